@@ -1,0 +1,448 @@
+"""oracle/r_side.py — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Plain numpy / pure-Python restatement of the R functions that sit either side
+of the U_NZentries hot path in GPvecchia (reference checked out read-only at
+/root/reference; every function cites the file:line it follows).  Written as
+slow, literal loops on purpose: it is the checker, never the thing measured or
+shipped.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import it.
+
+PARITY STATUS: "parity unpinned" against reference-run output (R is absent from
+this image, the package cannot be loaded).  Pinned by the identities the
+reference itself documents: m = n-1 reproduces the exact multivariate normal
+density (vignettes/GPvecchia_vignette.Rmd:129-139) for cond.yz in {z, y, SGV},
+and U U^T equals the joint precision of (y, z).
+
+All index arrays here are 1-based with NaN/0 for "missing", exactly like the R
+objects, so that the layout contract of R/U_sparsity.R is exercised literally.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+# ----------------------------------------------------------------------------
+# C restatement loader (oracle/u_nzentries_oracle.c)
+# ----------------------------------------------------------------------------
+def build_c_oracle(force: bool = False) -> str:
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "u_nzentries_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build_c_oracle())
+        dp = ctypes.POINTER(ctypes.c_double)
+        lp = ctypes.POINTER(ctypes.c_long)
+        _LIB.oracle_U_NZentries.restype = ctypes.c_long
+        _LIB.oracle_U_NZentries.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                            ctypes.c_int, dp, lp, dp, dp, dp, ctypes.c_int, dp, dp, dp]
+        _LIB.oracle_U_NZentries_mat.restype = ctypes.c_long
+        _LIB.oracle_U_NZentries_mat.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_long, ctypes.c_int,
+                                                lp, dp, dp, dp, dp]
+        _LIB.oracle_MaternFun.argtypes = [dp, ctypes.c_long, dp, dp]
+        _LIB.oracle_EsqeFun.argtypes = [dp, ctypes.c_long, dp, dp]
+        _LIB.oracle_max_threads.restype = ctypes.c_int
+    return _LIB
+
+
+def _dptr(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def max_threads() -> int:
+    return int(_lib().oracle_max_threads())
+
+
+def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covType, covparms):
+    """R/RcppExports.R:22-24 -> src/U_NZentries.cpp:25-118 (through the C restatement).
+
+    revNNarray: (Nlocs, p) 1-based with 0 for missing (R/createU.R:146-147).
+    Returns dict(Lentries=(Nlocs,p), Zentries=(2n,), n_failed)."""
+    locs = np.asfortranarray(locs, dtype=np.float64)
+    Nlocs, d = locs.shape
+    nn = np.asfortranarray(np.nan_to_num(np.asarray(revNNarray, dtype=np.float64), nan=0.0).astype(np.int64))
+    p = nn.shape[1]
+    cond = np.asfortranarray(np.nan_to_num(np.asarray(revCondOnLatent, dtype=np.float64), nan=0.0))
+    nug = np.ascontiguousarray(nuggets, dtype=np.float64)
+    nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)
+    cp = np.ascontiguousarray(covparms, dtype=np.float64)
+    code = {"matern": 0, "esqe": 1}.get(covType, 99)
+    L = np.zeros((Nlocs, p), dtype=np.float64, order="F")
+    Z = np.zeros(2 * int(n), dtype=np.float64)
+    nf = _lib().oracle_U_NZentries(int(Ncores), int(n), int(Nlocs), int(d), int(p), _dptr(locs),
+                                   nn.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), _dptr(cond), _dptr(nug),
+                                   _dptr(nugo), code, _dptr(cp), _dptr(L), _dptr(Z))
+    if nf < 0:
+        raise ValueError(f"{covType} covariance is not implemented")      # src/U_NZentries.cpp:27-29
+    return dict(Lentries=np.array(L), Zentries=Z, n_failed=int(nf))
+
+
+def U_NZentries_mat(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covVals, covparms):
+    """R/RcppExports.R:26-28 -> src/U_NZentries.cpp:126-197."""
+    Nlocs = np.asarray(locs).shape[0]
+    nn = np.asfortranarray(np.nan_to_num(np.asarray(revNNarray, dtype=np.float64), nan=0.0).astype(np.int64))
+    p = nn.shape[1]
+    nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)
+    cv = np.asfortranarray(covVals, dtype=np.float64)
+    L = np.zeros((Nlocs, p), dtype=np.float64, order="F")
+    Z = np.zeros(2 * int(n), dtype=np.float64)
+    nf = _lib().oracle_U_NZentries_mat(int(Ncores), int(n), int(Nlocs), int(p),
+                                       nn.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), _dptr(nugo), _dptr(cv),
+                                       _dptr(L), _dptr(Z))
+    return dict(Lentries=np.array(L), Zentries=Z, n_failed=int(nf))
+
+
+# ----------------------------------------------------------------------------
+# covariance functions (numpy; general nu included)
+# ----------------------------------------------------------------------------
+def MaternFun(distmat, covparms):
+    """src/Matern.cpp:24-86, including the general-nu Bessel branch (:72-84).
+
+    Note the general branch has no sqrt(2 nu) scaling of the distance (a quirk
+    of the reference that is reproduced, not fixed)."""
+    from scipy.special import gamma, kv
+    d = np.asarray(distmat, dtype=np.float64)
+    sig2, rng, nu = (float(x) for x in covparms[:3])
+    out = np.empty_like(d)
+    z = d == 0
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        s = d / rng
+        if nu == 0.5:
+            v = sig2 * np.exp(-s)
+        elif nu == 1.5:
+            v = sig2 * (1 + np.sqrt(3) * s) * np.exp(-np.sqrt(3) * s)
+        elif nu == 2.5:
+            v = sig2 * np.exp(-s * np.sqrt(5)) * (1 + np.sqrt(5) * s + 5 * s * s / 3)
+        else:
+            normcon = sig2 / (2.0 ** (nu - 1) * gamma(nu))
+            v = normcon * s ** nu * kv(nu, s)
+    out[...] = v
+    out[z] = sig2
+    return out
+
+
+def EsqeFun(distmat, covparms):
+    """src/Esqe.cpp:17-39."""
+    d = np.asarray(distmat, dtype=np.float64)
+    v = covparms[0] * np.exp(-(d / covparms[1])) + covparms[2] * np.exp(-((d / covparms[3]) ** 2))
+    v = np.where(d == 0, covparms[0] + covparms[2], v)
+    return v
+
+
+def rdist(a, b=None):
+    a = np.asarray(a, dtype=np.float64)
+    b = a if b is None else np.asarray(b, dtype=np.float64)
+    ssq = np.zeros((a.shape[0], b.shape[0]))
+    for t in range(a.shape[1]):
+        ssq += (a[:, t][:, None] - b[:, t][None, :]) ** 2
+    return np.sqrt(ssq)
+
+
+# ----------------------------------------------------------------------------
+# orderings (R/ordering_functions.R, src/MaxMin.cpp)
+# ----------------------------------------------------------------------------
+def order_coordinate(locs, coordinate=None):
+    """R/ordering_functions.R:126-128 (R's order() is stable). Returns 1-based."""
+    locs = np.asarray(locs, dtype=np.float64)
+    cols = list(range(locs.shape[1])) if coordinate is None else list(coordinate)
+    return np.argsort(locs[:, cols].sum(axis=1), kind="stable") + 1
+
+
+def order_maxmin_exact(locs):
+    """R/ordering_functions.R:147-150 -> src/MaxMin.cpp:661-738.
+
+    Exact max-min-distance ordering; first point = closest to the centroid,
+    strict '<' so the lowest index wins ties (src/MaxMin.cpp:675-707).  The
+    reference's heap-based algorithm is quasi-linear; this restatement is the
+    O(n^2) definition.  Ties in the max-min distance (regular grids) are broken
+    towards the lowest index here; the reference's tie order is an artefact of
+    its heap and is unpinned.  Returns 1-based indices."""
+    locs = np.asarray(locs, dtype=np.float64)
+    n, dim = locs.shape
+    avg = np.zeros(dim)
+    for i in range(n):
+        avg += locs[i]
+    avg /= n
+    d2 = np.zeros(n)
+    for j in range(dim):
+        d2 += (locs[:, j] - avg[j]) * (locs[:, j] - avg[j])
+    first = int(np.argmin(d2))
+    order = [first]
+    mind = np.sqrt(((locs - locs[first]) ** 2).sum(axis=1))
+    mind[first] = -1.0
+    for _ in range(1, n):
+        nxt = int(np.argmax(mind))
+        order.append(nxt)
+        dn = np.sqrt(((locs - locs[nxt]) ** 2).sum(axis=1))
+        mind = np.minimum(mind, dn)
+        mind[order] = -1.0
+    return np.asarray(order, dtype=np.int64) + 1
+
+
+# ----------------------------------------------------------------------------
+# conditioning sets (R/NN_kdtree.R)
+# ----------------------------------------------------------------------------
+def findOrderedNN(locs, m):
+    """R/NN_kdtree.R:73-83 — brute-force ordered nearest neighbours.
+
+    Row j (1-based) = the min(m+1, j) nearest points among locs[1..j] (self
+    included, distance 0), ascending distance, R's stable order() => lower index
+    wins ties.  NaN-padded on the right.  This is the semantic definition the
+    package relies on; for d >= 2 the package calls GpGp::find_ordered_nn
+    (R/vecchia_specify.R:159, not vendored), which implements the same
+    definition up to tie-breaking."""
+    locs = np.asarray(locs, dtype=np.float64)
+    n = locs.shape[0]
+    NN = np.full((n, m + 1), np.nan)
+    for j in range(n):
+        dv = rdist(locs[: j + 1], locs[j: j + 1])[:, 0]
+        o = np.argsort(dv, kind="stable")[: min(m + 1, j + 1)]
+        NN[j, : len(o)] = o + 1
+    return NN
+
+
+def whichCondOnLatent(NNarray, firstind_pred=None):
+    """R/whichCondOnLatent.R:2-26 — the SGV rule, literal (including R's
+    is.element(NA, NA) == TRUE semantics on the first rows)."""
+    NN = np.asarray(NNarray, dtype=np.float64)
+    n, p = NN.shape
+    m = p - 1
+    if firstind_pred is None:
+        firstind_pred = n + 1
+    Cond = np.full((n, p), np.nan)
+    Cond[0, 0] = 1.0
+
+    def is_element(x, table):
+        # R: match() treats NA as matching NA
+        res = np.zeros(len(x), dtype=bool)
+        tab_has_na = bool(np.any(np.isnan(table)))
+        tabvals = set(table[~np.isnan(table)].tolist())
+        for i, v in enumerate(x):
+            res[i] = tab_has_na if np.isnan(v) else (v in tabvals)
+        return res
+
+    for k in range(1, n):
+        latents = np.zeros(p)                  # R: rep(0,m) grown to m+1 by assignment
+        for ind in range(1, p):
+            l = NN[k, ind]
+            if not np.isnan(l) and l < firstind_pred:
+                li = int(l) - 1
+                latents[ind] = np.sum(is_element(NN[k], NN[li] * Cond[li]))
+        # latents[0] stays 0 (R vector index 1 is never assigned => 0)
+        best = int(np.where(latents == latents.max())[0][0])   # :19 first maximum
+        ind = int(NN[k, best]) - 1
+        Cond[k] = is_element(NN[k], NN[ind] * Cond[ind]).astype(float)
+        with np.errstate(invalid="ignore"):
+            Cond[k, NN[k] >= firstind_pred] = 1.0
+        Cond[k, 0] = 1.0
+        Cond[k, np.isnan(NN[k])] = np.nan
+    return Cond
+
+
+# ----------------------------------------------------------------------------
+# U_sparsity / vecchia_specify (R/U_sparsity.R, R/vecchia_specify.R)
+# ----------------------------------------------------------------------------
+def U_sparsity(locs, NNarray, obs, Cond):
+    """R/U_sparsity.R:5-81, literal."""
+    NN = np.asarray(NNarray, dtype=np.float64)
+    Cond = np.asarray(Cond, dtype=np.float64)
+    nnp = np.asarray(locs).shape[0]
+    obs = np.asarray(obs, dtype=bool)
+    n = int(obs.sum())
+    size = nnp + n
+    latent_map = np.zeros(nnp, dtype=np.int64)
+    observed_map = np.full(nnp, -1, dtype=np.int64)
+    cur = 1
+    for k in range(nnp):                                  # :19-29
+        latent_map[k] = cur
+        cur += 1
+        if obs[k]:
+            observed_map[k] = cur
+            cur += 1
+    revNN = NN[:, ::-1].copy()                            # :32
+    revCond = Cond[:, ::-1].copy()                        # :33
+    rowp, coli = [], []
+    for k in range(nnp):                                  # :39-56
+        inds = revNN[k]
+        ok = ~np.isnan(inds)
+        inds0 = inds[ok].astype(np.int64) - 1
+        rc = revCond[k, ok] == 1.0
+        cur_row = latent_map[k]
+        cols = np.where(rc, latent_map[inds0], observed_map[inds0])
+        rowp.extend([cur_row] * len(inds0))
+        coli.extend(cols.tolist())
+    Zrow, Zcol = [], []
+    for k in range(nnp):                                  # :59-69
+        if obs[k]:
+            Zrow.extend([observed_map[k]] * 2)
+            Zcol.extend([latent_map[k], observed_map[k]])
+    return dict(revNNarray=revNN, revCond=revCond, n_cores=os.cpu_count(), size=size,
+                rowpointers=np.asarray(rowp + Zrow, dtype=np.int64),
+                colindices=np.asarray(coli + Zcol, dtype=np.int64),
+                y_ind=latent_map, observed_map=observed_map)
+
+
+def vecchia_specify(locs, m, ordering=None, cond_yz=None, NNarray=None):
+    """R/vecchia_specify.R:29-240 — the no-prediction, conditioning='NN' subset.
+
+    ordering in {'none','coord','maxmin'}; cond_yz in {'z','y','SGV'}.
+    NNarray may be supplied (1-based, NaN padded) to bypass the NN search."""
+    locs = np.asarray(locs, dtype=np.float64)
+    n, dim = locs.shape
+    if m > n:                                                       # :53-56
+        m = n - 1
+    if ordering is None:                                            # :83-85
+        ordering = "coord" if dim == 1 else "maxmin"
+    if cond_yz is None:                                             # :92-96
+        cond_yz = "SGV"
+    if ordering == "coord":                                         # :102
+        ord_ = order_coordinate(locs)
+    elif ordering == "maxmin":                                      # :103-106
+        o = order_maxmin_exact(locs)
+        cut = min(n, 9)
+        ord_ = np.concatenate([o[:1], o[cut:], o[1:cut]])
+    elif ordering == "none":                                        # :109-110
+        ord_ = np.arange(1, n + 1)
+    else:
+        raise ValueError(ordering)
+    locsord = locs[ord_ - 1]
+    obs = np.ones(n, dtype=bool)
+    if NNarray is None:
+        NNarray = findOrderedNN(locsord, m)                         # :157-159 (semantic twin)
+    NNarray = np.asarray(NNarray, dtype=np.float64)
+    if cond_yz == "SGV":                                            # :182-183
+        Cond = whichCondOnLatent(NNarray, firstind_pred=n + 1)
+    elif cond_yz == "y":                                            # :186-187
+        Cond = np.full(NNarray.shape, np.nan)
+        Cond[~np.isnan(NNarray)] = 1.0
+    elif cond_yz == "z":                                            # :189-190
+        Cond = np.full(NNarray.shape, np.nan)
+        Cond[~np.isnan(NNarray)] = 0.0
+        Cond[:, 0] = 1.0
+    else:
+        raise ValueError(cond_yz)
+    U_prep = U_sparsity(locsord, NNarray, obs, Cond)                # :230
+    return dict(locsord=locsord, obs=obs, ord=ord_, ord_z=ord_.copy(), ord_pred="general",
+                U_prep=U_prep, cond_yz=cond_yz, ic0=False, conditioning="NN")
+
+
+# ----------------------------------------------------------------------------
+# createU / vecchia_likelihood (R/createU.R, R/vecchia_likelihood.R, R/vecchia_prediction.R)
+# ----------------------------------------------------------------------------
+def createU(va, covparms, nuggets, covmodel="matern"):
+    """R/createU.R:65-86,141-163,195-199 — NN branch, non-zy, nuggets > 0.
+
+    Returns dict with dense U (size x size), latent mask, ord_z, plus the raw
+    U_entries for parity tests."""
+    n = int(np.sum(va["obs"]))
+    prep = va["U_prep"]
+    size = prep["size"]
+    latent = np.isin(np.arange(1, size + 1), prep["y_ind"])
+    ord_ = va["ord"]
+    nug = np.asarray(nuggets, dtype=np.float64)
+    if nug.size == 1:                                               # :74
+        nug = np.repeat(nug, n)
+    nuggets_all = np.concatenate([nug, np.zeros(int(latent.sum()) - n)])   # :75
+    nuggets_all_ord = nuggets_all[ord_ - 1]                         # :77
+    nuggets_ord = nuggets_all[va["ord_z"] - 1]                      # :78
+    revNN = prep["revNNarray"].copy()
+    revCond = prep["revCond"].copy()
+    if np.any(nug == 0):                                            # :83-86
+        zero_idx = np.where(nuggets_ord == 0)[0] + 1
+        revCond[np.isin(revNN, zero_idx)] = 1.0
+    revNN0 = np.nan_to_num(revNN, nan=0.0)                          # :146-147
+    if isinstance(covmodel, str):
+        ent = U_NZentries(prep["n_cores"], n, va["locsord"], revNN0, revCond, nuggets_all_ord,
+                          nuggets_ord, covmodel, covparms)          # :152-154
+    else:
+        ent = U_NZentries_mat(prep["n_cores"], n, va["locsord"], revNN0, revCond, nuggets_all_ord,
+                              nuggets_ord, np.asarray(covmodel), covparms)   # :149-151
+    # :158-159 — row-major walk of Lentries keeping the first n0 entries of each row
+    L = ent["Lentries"]
+    n0 = (~np.isnan(revNN)).sum(axis=1)
+    vals = np.concatenate([L[k, : n0[k]] for k in range(L.shape[0])] + [ent["Zentries"]])   # :160
+    U = np.zeros((size, size))
+    # :161-162 sparseMatrix(i=colindices, j=rowpointers, x=...) (duplicates would be summed)
+    np.add.at(U, (prep["colindices"] - 1, prep["rowpointers"] - 1), vals)
+    return dict(U=U, latent=latent, ord=ord_, obs=va["obs"], ord_z=va["ord_z"], ord_pred=va["ord_pred"],
+                cond_yz=va["cond_yz"], ic0=va["ic0"], U_entries=ent,
+                triplets=(prep["colindices"].copy(), prep["rowpointers"].copy(), vals))
+
+
+def U2V(U_obj):
+    """R/vecchia_prediction.R:62-83 (non-zy, non-obspred): V = t(chol(rev(U_y U_y^T)))."""
+    Uy = U_obj["U"][U_obj["latent"], :]
+    W = Uy @ Uy.T                                                   # :74
+    Wrev = W[::-1, ::-1]                                            # :75
+    return np.linalg.cholesky(Wrev)                                 # :80 (lower = t(upper chol))
+
+
+def vecchia_likelihood_U(z, U_obj):
+    """R/vecchia_likelihood.R:63-99."""
+    from scipy.linalg import solve_triangular
+    U = U_obj["U"]
+    latent = U_obj["latent"]
+    zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]      # :68
+    const = np.sum(~latent) * np.log(2 * np.pi)                     # :71
+    z1 = U[~latent, :].T @ zord                                     # :74
+    quadform_num = np.sum(z1 ** 2)                                  # :75
+    logdet_num = -2 * np.sum(np.log(np.diag(U)))                    # :76
+    if latent.sum() == 0:                                           # :79-81
+        logdet_denom = quadform_denom = 0.0
+    else:
+        z2 = U[latent, :] @ z1                                      # :85-86
+        V = U2V(U_obj)                                              # :87
+        z3 = solve_triangular(V, z2[::-1], lower=True)              # :88
+        quadform_denom = np.sum(z3 ** 2)                            # :89
+        logdet_denom = -2 * np.sum(np.log(np.diag(V)))              # :90
+    neg2loglik = logdet_num - logdet_denom + quadform_num - quadform_denom + const   # :95
+    return -neg2loglik / 2                                          # :96
+
+
+def vecchia_likelihood(z, va, covparms, nuggets, covmodel="matern"):
+    """R/vecchia_likelihood.R:14-27 (without the NA handling of removeNAs)."""
+    return vecchia_likelihood_U(z, createU(va, covparms, nuggets, covmodel))
+
+
+def separable_loglik_condz(va, U_entries, z, nuggets):
+    """Closed form of vecchia_likelihood_U when cond.yz == 'z' (W = U_y U_y^T is
+    diagonal): derived from R/vecchia_likelihood.R:63-99, R/vecchia_prediction.R:74.
+    Used to pin the device epilogue; returns (loglik, partial sums)."""
+    prep = va["U_prep"]
+    revNN = prep["revNNarray"]
+    revCond = prep["revCond"]
+    L = U_entries["Lentries"]
+    n, p = revNN.shape
+    zord = np.asarray(z, dtype=np.float64)[va["ord_z"] - 1]
+    tau = np.asarray(nuggets, dtype=np.float64)
+    tau = np.repeat(tau, n) if tau.size == 1 else tau[va["ord_z"] - 1]
+    s = np.zeros(6)
+    for k in range(n):
+        ok = ~np.isnan(revNN[k])
+        n0 = int(ok.sum())
+        idx = revNN[k, ok].astype(np.int64) - 1
+        c = revCond[k, ok]
+        M = L[k, :n0]
+        d = M[n0 - 1]
+        a = float(np.sum(M[: n0 - 1] * zord[idx[: n0 - 1]] * (c[: n0 - 1] == 0)))
+        w = d * d + 1.0 / tau[k]
+        s[0] += np.log(d)
+        s[1] += np.log(tau[k])
+        s[2] += np.log(w)
+        s[3] += a * a
+        s[4] += zord[k] ** 2 / tau[k]
+        s[5] += (d * a - zord[k] / tau[k]) ** 2 / w
+    loglik = -0.5 * (-2 * s[0] + s[1] + s[2] + s[3] + s[4] - s[5] + n * np.log(2 * np.pi))
+    return loglik, s

@@ -1,0 +1,215 @@
+"""CPU tests of the oracle itself (oracle/ is the checker for every GPU parity
+test, so it is pinned first).  The reference has no golden vectors for the
+U_NZentries path; what it does state are identities, which
+are asserted here:
+  * tests/testthat/test-MaternFun.r:5-41 — closed forms of MaternFun
+  * vignettes/GPvecchia_vignette.Rmd:129-139 — m = n-1 reproduces dmvnorm
+plus LAPACK (scipy dpotrf/dtrtrs = what arma::chol/solve call) and mpmath."""
+import numpy as np
+import pytest
+
+from oracle import r_side as R
+
+
+def test_maternfun_closed_forms_reference_test():
+    # literal restatement of tests/testthat/test-MaternFun.r (R RNG replaced by numpy)
+    rng = np.random.default_rng(1988)
+    locs = rng.random((100, 2))
+    D = R.rdist(locs)
+    sig2, rg = 1.0, 0.2
+    s = D / rg
+    naive05 = np.exp(-s) * sig2
+    naive15 = sig2 * (1 + np.sqrt(3) * s) * np.exp(-np.sqrt(3) * s)
+    naive25 = sig2 * (1 + np.sqrt(5) * s + 5 / 3 * s ** 2) * np.exp(-np.sqrt(5) * s)
+    for nu, naive in ((0.5, naive05), (1.5, naive15), (2.5, naive25)):
+        cp = np.array([sig2, rg, nu])
+        out = np.empty_like(D)
+        R._lib().oracle_MaternFun(R._dptr(np.ascontiguousarray(D)), D.size, R._dptr(cp), R._dptr(out))
+        assert np.sum(np.abs(naive - out)) < 1e-10          # expect_lt(sum(abs(D..)), 1e-10)
+        assert np.sum(np.abs(naive - R.MaternFun(D, cp))) < 1e-10
+        assert np.all(np.diag(out) == sig2)                 # dist == 0 -> sigma^2 exactly
+
+
+def test_matern_general_nu_continuity_quirk():
+    # src/Matern.cpp:72-84: general branch has no sqrt(2nu) scaling => differs from nu==1.5 branch
+    d = np.array([0.0, 0.1, 0.3])
+    a = R.MaternFun(d, [1.0, 0.2, 1.5])
+    b = R.MaternFun(d, [1.0, 0.2, 1.5 + 1e-9])
+    assert a[0] == b[0] == 1.0
+    assert abs(a[1] - b[1]) > 1e-3
+    # general branch equals the textbook Matern evaluated at range/sqrt(2nu)... i.e. plain K_nu form
+    from scipy.special import gamma, kv
+    nu = 0.8
+    s = d[1:] / 0.2
+    np.testing.assert_allclose(R.MaternFun(d, [2.0, 0.2, nu])[1:],
+                               2.0 * 2 ** (1 - nu) / gamma(nu) * s ** nu * kv(nu, s), rtol=1e-14)
+
+
+def test_esqe():
+    d = np.array([0.0, 0.1, 0.5])
+    cp = np.array([1.0, 0.3, 0.5, 0.2])
+    out = np.empty(3)
+    R._lib().oracle_EsqeFun(R._dptr(d), 3, R._dptr(cp), R._dptr(out))
+    np.testing.assert_allclose(out, R.EsqeFun(d, cp), rtol=1e-15)
+    assert out[0] == 1.5
+
+
+def test_kat_six_points(kat):
+    va = R.vecchia_specify(kat["locs"], kat["m"], ordering="none", cond_yz="z")
+    assert np.array_equal(np.nan_to_num(va["U_prep"]["revNNarray"][:, ::-1]),
+                          np.array([[1, 0, 0], [2, 1, 0], [3, 1, 2], [4, 2, 3], [5, 1, 2], [6, 3, 5]]))
+    Uo = R.createU(va, kat["covparms"], kat["nugget"])
+    np.testing.assert_allclose(Uo["U_entries"]["Lentries"], kat["Lentries_z"], rtol=0, atol=2e-15)
+    np.testing.assert_allclose(Uo["U_entries"]["Zentries"][::2], -3.162277660168379, rtol=1e-15)
+    ll = R.vecchia_likelihood_U(kat["z"], Uo)
+    assert abs(ll - kat["loglik_z"]) < 1e-14
+    ll2, _ = R.separable_loglik_condz(va, Uo["U_entries"], kat["z"], kat["nugget"])
+    assert abs(ll2 - kat["loglik_z"]) < 1e-14
+    va = R.vecchia_specify(kat["locs"], kat["m"], ordering="none", cond_yz="SGV")
+    assert np.array_equal(np.nan_to_num(va["U_prep"]["revCond"], nan=-1),
+                          np.array([[-1, -1, 1], [-1, 1, 1], [1, 1, 1], [1, 1, 1], [1, 1, 1], [0, 1, 1]]))
+    Uo = R.createU(va, kat["covparms"], kat["nugget"])
+    np.testing.assert_allclose(Uo["U_entries"]["Lentries"][-1], kat["last_row_sgv"], atol=2e-15)
+    assert abs(R.vecchia_likelihood_U(kat["z"], Uo) - kat["loglik_sgv"]) < 1e-14
+
+
+@pytest.mark.parametrize("cond", ["z", "y", "SGV"])
+@pytest.mark.parametrize("ordering", ["none", "maxmin", "coord"])
+def test_m_equals_n_minus_1_is_exact(cond, ordering):
+    # vignettes/GPvecchia_vignette.Rmd:129-139: vecchia_likelihood vs dmvnorm
+    from scipy.stats import multivariate_normal
+    rng = np.random.default_rng(0)
+    n = 40
+    locs = rng.random((n, 2))
+    z = rng.standard_normal(n)
+    cp = [1.3, 0.3, 1.5]
+    S = R.MaternFun(R.rdist(locs), cp) + 0.2 * np.eye(n)
+    exact = multivariate_normal.logpdf(z, np.zeros(n), S)
+    va = R.vecchia_specify(locs, n - 1, ordering=ordering, cond_yz=cond)
+    assert abs(R.vecchia_likelihood(z, va, cp, 0.2) - exact) < 1e-11
+
+
+def test_U_Ut_is_joint_precision():
+    # with m = n-1, U U^T = precision of the interleaved (y1,z1,y2,z2,...) vector
+    rng = np.random.default_rng(3)
+    n = 15
+    locs = rng.random((n, 2))
+    cp = [1.0, 0.4, 0.5]
+    tau = 0.3
+    va = R.vecchia_specify(locs, n - 1, ordering="none", cond_yz="SGV")
+    U = R.createU(va, cp, tau)["U"]
+    K = R.MaternFun(R.rdist(locs), cp)
+    J = np.zeros((2 * n, 2 * n))
+    yi, zi = np.arange(0, 2 * n, 2), np.arange(1, 2 * n, 2)
+    J[np.ix_(yi, yi)] = K
+    J[np.ix_(yi, zi)] = K
+    J[np.ix_(zi, yi)] = K
+    J[np.ix_(zi, zi)] = K + tau * np.eye(n)
+    np.testing.assert_allclose(U @ U.T, np.linalg.inv(J), rtol=0, atol=1e-8)
+    assert np.allclose(U, np.triu(U))
+
+
+def _random_case(n, m, d, seed, cond="SGV"):
+    rng = np.random.default_rng(seed)
+    locs = rng.random((n, d))
+    va = R.vecchia_specify(locs, m, ordering="none", cond_yz=cond)
+    return locs, va
+
+
+@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5])
+def test_rows_against_lapack(nu):
+    # arma::chol -> dpotrf('U'), arma::solve(R, e) -> triangular solve
+    from scipy.linalg import lapack
+    locs, va = _random_case(300, 12, 2, 5)
+    cp = [1.2, 0.15, nu]
+    tau = 0.05
+    Uo = R.createU(va, cp, tau)
+    L = Uo["U_entries"]["Lentries"]
+    revNN, revCond = va["U_prep"]["revNNarray"], va["U_prep"]["revCond"]
+    for k in range(0, 300, 7):
+        ok = ~np.isnan(revNN[k])
+        idx = revNN[k, ok].astype(int) - 1
+        S = R.MaternFun(R.rdist(locs[idx]), cp) + np.diag(tau * (1 - revCond[k, ok]))
+        Rm, info = lapack.dpotrf(S, lower=0)
+        assert info == 0
+        e = np.zeros(len(idx)); e[-1] = 1
+        x, info = lapack.dtrtrs(Rm, e, lower=0)
+        np.testing.assert_allclose(L[k, :len(idx)], x, rtol=0, atol=1e-11 * np.abs(x).max())
+        assert np.all(L[k, len(idx):] == 0)
+
+
+def test_row_against_mpmath():
+    import mpmath as mp
+    mp.mp.dps = 50
+    locs, va = _random_case(60, 10, 2, 11, cond="z")
+    cp = [1.0, 0.2, 1.5]
+    tau = 0.1
+    L = R.createU(va, cp, tau)["U_entries"]["Lentries"]
+    revNN, revCond = va["U_prep"]["revNNarray"], va["U_prep"]["revCond"]
+    for k in (17, 59):
+        idx = revNN[k].astype(int) - 1
+        c = revCond[k]
+        n0 = len(idx)
+        S = mp.matrix(n0, n0)
+        for a in range(n0):
+            for b in range(n0):
+                dd = mp.sqrt(sum((mp.mpf(float(locs[idx[a], t])) - mp.mpf(float(locs[idx[b], t]))) ** 2
+                                 for t in range(2)))
+                s = dd / mp.mpf(cp[1])
+                v = mp.mpf(cp[0]) * (1 + mp.sqrt(3) * s) * mp.exp(-mp.sqrt(3) * s)
+                S[a, b] = v + (mp.mpf(tau) * (1 - int(c[a])) if a == b else 0)
+        e = mp.matrix(n0, 1); e[n0 - 1] = 1
+        sol = mp.lu_solve(S, e)                      # S^{-1} e_last
+        x = sol / mp.sqrt(sol[n0 - 1])               # R^{-1} e = S^{-1} e * R_ll, R_ll = 1/sqrt((S^{-1})_ll)
+        ref = np.array([float(v) for v in x])
+        np.testing.assert_allclose(L[k], ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+
+
+def test_failure_and_edge_semantics():
+    # duplicate locations with latent conditioning => singular block => zero row, counted (src/U_NZentries.cpp:60-66)
+    locs = np.array([[0.0, 0.0], [0.0, 0.0], [1.0, 1.0]])
+    revNN = np.array([[0, 0, 1], [0, 1, 2], [1, 2, 3]], float)
+    revCond = np.array([[0, 0, 1], [0, 1, 1], [1, 1, 1]], float)
+    out = R.U_NZentries(1, 3, locs, revNN, revCond, np.full(3, .1), np.full(3, .1), "matern", [1, .5, 1.5])
+    assert out["n_failed"] == 2
+    assert np.all(out["Lentries"][1] == 0) and np.all(out["Lentries"][2] == 0)
+    assert out["Lentries"][0, 0] == 1.0
+    # Inf nugget (VL builds them, R/vecchia_laplace_NR.R:108, but removeNAs() replaces them by
+    # var(z)*1e8 before createU, R/vecchia_likelihood.R:55): literal :47 gives Inf*(1-1) = NaN on the
+    # location's OWN row (self is always latent) => that row fails; as an observed-conditioned
+    # neighbour of another row the weight is exactly 0.
+    revCond[1] = [0, 0, 1]
+    revCond[2] = [0, 0, 1]
+    locs2 = np.array([[0.0, 0.0], [0.3, 0.0], [1.0, 1.0]])
+    nug = np.array([np.inf, .1, .1])
+    out = R.U_NZentries(1, 3, locs2, revNN, revCond, nug, nug, "matern", [1, .5, 1.5])
+    assert out["n_failed"] == 1 and np.all(out["Lentries"][0] == 0)
+    assert out["Lentries"][1, 0] == 0.0 and out["Lentries"][1, 1] == 1.0
+    assert out["Lentries"][2, 0] == 0.0 and np.isfinite(out["Lentries"]).all()
+    assert out["Zentries"][0] == 0.0                      # -1/sqrt(Inf)
+    big = np.array([1e8, .1, .1])                         # what removeNAs() really passes
+    out = R.U_NZentries(1, 3, locs2, revNN, revCond, big, big, "matern", [1, .5, 1.5])
+    assert out["n_failed"] == 0 and abs(out["Lentries"][2, 0]) < 1e-7
+    # zero nugget => Zentries = -/+Inf (handled later in R, R/createU.R:173-193)
+    out = R.U_NZentries(1, 3, locs2, revNN, revCond, np.zeros(3), np.zeros(3), "matern", [1, .5, 1.5])
+    assert np.isinf(out["Zentries"]).all()
+    with pytest.raises(ValueError):
+        R.U_NZentries(1, 3, locs2, revNN, revCond, nug, nug, "gauss", [1, .5, 1.5])
+
+
+def test_U_NZentries_mat_matches_kernel_path_without_nugget():
+    locs, va = _random_case(50, 6, 2, 2, cond="y")
+    cp = [1.0, 0.3, 0.5]
+    K = R.MaternFun(R.rdist(locs), cp)
+    a = R.createU(va, cp, 0.2, covmodel="matern")["U_entries"]["Lentries"]
+    b = R.createU(va, cp, 0.2, covmodel=K)["U_entries"]["Lentries"]
+    np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)   # cond 'y' => no nugget inside blocks
+
+
+def test_whichCondOnLatent_properties():
+    _, va = _random_case(80, 5, 2, 9)
+    C = va["U_prep"]["revCond"][:, ::-1]
+    NN = va["U_prep"]["revNNarray"][:, ::-1]
+    assert np.all(C[:, 0] == 1)
+    assert np.array_equal(np.isnan(C), np.isnan(NN))
+    assert set(np.unique(C[~np.isnan(C)])) <= {0.0, 1.0}
