@@ -203,7 +203,7 @@ def test_U_NZentries_mat_matches_kernel_path_without_nugget():
     K = R.MaternFun(R.rdist(locs), cp)
     a = R.createU(va, cp, 0.2, covmodel="matern")["U_entries"]["Lentries"]
     b = R.createU(va, cp, 0.2, covmodel=K)["U_entries"]["Lentries"]
-    np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)   # cond 'y' => no nugget inside blocks
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-12)   # cond 'y' => no nugget inside blocks
 
 
 def test_whichCondOnLatent_properties():
