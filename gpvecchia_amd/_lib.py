@@ -1,0 +1,112 @@
+"""ctypes binding of libgpvecchia_hip.so (include/gpvecchia.h).
+
+The shared library is the product; this module only loads it and declares the
+prototypes.  There is deliberately no Python/NumPy compute fallback: if the
+library is missing it is built (hipcc), and if that fails the import error
+propagates; if no GPU is present every compute entry raises GpvError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpvecchia_hip.so")
+NSUMS = 8
+
+GPV_WANT_U = 1
+GPV_WANT_LOGLIK_Z = 2
+GPV_WANT_NUMERATOR = 4
+
+# every symbol include/gpvecchia.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "gpv_status_string", "gpv_version", "gpv_device_count", "gpv_max_p",
+    "gpv_U_NZentries", "gpv_U_NZentries_mat", "gpv_MaternFun", "gpv_EsqeFun",
+    "gpv_plan_create", "gpv_plan_destroy", "gpv_plan_set_data", "gpv_plan_eval",
+    "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
+    "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms",
+    "gpv_loglik_z_from_sums", "gpv_numerator_from_sums",
+]
+
+
+class GpvError(RuntimeError):
+    def __init__(self, status: int, where: str = ""):
+        self.status = status
+        msg = lib().gpv_status_string(status).decode()
+        super().__init__(f"libgpvecchia_hip: {where}: {msg} (status {status})")
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    L = C.CDLL(LIB_PATH)
+    dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+    i64 = C.c_int64
+    L.gpv_status_string.restype = C.c_char_p
+    L.gpv_status_string.argtypes = [C.c_int]
+    L.gpv_version.restype = C.c_int
+    L.gpv_device_count.argtypes = [ip]
+    L.gpv_max_p.restype = C.c_int
+    L.gpv_U_NZentries.restype = None
+    L.gpv_U_NZentries.argtypes = [ip, ip, ip, ip, ip, dp, ip, ip, dp, dp, C.POINTER(C.c_char_p), dp, ip, dp, dp, ip, ip]
+    L.gpv_U_NZentries_mat.restype = None
+    L.gpv_U_NZentries_mat.argtypes = [ip, ip, ip, ip, ip, dp, dp, dp, dp, ip, ip]
+    L.gpv_MaternFun.restype = None
+    L.gpv_MaternFun.argtypes = [dp, ip, dp, dp, ip]
+    L.gpv_EsqeFun.restype = None
+    L.gpv_EsqeFun.argtypes = [dp, ip, dp, dp, ip]
+    L.gpv_plan_create.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_int, dp, ip, ip, i64, i64]
+    L.gpv_plan_destroy.argtypes = [vp]
+    L.gpv_plan_set_data.argtypes = [vp, dp]
+    L.gpv_plan_eval.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, i64, C.c_int, vp, vp]
+    L.gpv_plan_get_sums.argtypes = [vp, dp]
+    L.gpv_plan_get_Lentries.argtypes = [vp, dp]
+    L.gpv_plan_get_Zentries.argtypes = [vp, dp]
+    L.gpv_plan_Lentries_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.gpv_plan_rows.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.gpv_plan_last_kernel_ms.argtypes = [vp, dp]
+    L.gpv_loglik_z_from_sums.argtypes = [dp, i64, dp]
+    L.gpv_numerator_from_sums.argtypes = [dp, dp, dp]
+    _lib = L
+    return L
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def iptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().gpv_device_count(C.byref(n))
+    return int(n.value)
+
+
+def check(status: int, where: str):
+    if status != 0:
+        raise GpvError(int(status), where)
+
+
+NA_INTEGER = -2147483648
+
+
+def as_r_int_matrix(a):
+    """float/int matrix with NaN (R's NA) -> Fortran-ordered int32 with NA_INTEGER."""
+    a = np.asarray(a)
+    if a.dtype.kind == "f":
+        out = np.where(np.isnan(a), NA_INTEGER, a).astype(np.int32)
+    else:
+        out = a.astype(np.int32)
+    return np.asfortranarray(out)

@@ -1,0 +1,81 @@
+"""Build libgpvecchia_hip.so (gfx950) in-tree with hipcc.
+
+    python -m gpvecchia_amd.build [--force] [--jobs N]
+
+One translation unit per compiled row length (csrc/gpv_plist.h) so the kernels
+compile in parallel; objects are cached under csrc/build/ by source mtime.
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only container.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libgpvecchia_hip.so")
+ARCH = "gfx950"
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-variable"]
+
+
+def plist():
+    txt = open(os.path.join(CSRC, "gpv_plist.h")).read()
+    line = [l for l in txt.splitlines() if l.startswith("#define GPV_P_LIST")][0]
+    return [int(x) for x in re.findall(r"X\((\d+)\)", line)]
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _compile(args):
+    src, obj, extra, deps, force = args
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= _newest(deps + [src]):
+        return obj, 0.0
+    import time
+    t0 = time.time()
+    cmd = [HIPCC] + FLAGS + extra + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    return obj, time.time() - t0
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in ("gpv_internal.h", "gpv_sets_kernel.hpp", "gpv_plist.h")]
+    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gpvecchia.h"))
+    work = []
+    for P in plist():
+        work.append((os.path.join(CSRC, "gpv_sets_inst.hip"), os.path.join(BUILD, f"sets_p{P}.o"),
+                     [f"-DGPV_INST_P={P}"], hdrs, force))
+    work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), [], hdrs, force))
+    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), [], hdrs, force))
+    jobs = jobs or min(8, os.cpu_count() or 1)
+    with ThreadPoolExecutor(jobs) as ex:
+        res = list(ex.map(_compile, work))
+    objs = [o for o, _ in res]
+    if verbose:
+        for o, t in res:
+            if t:
+                print(f"  compiled {os.path.basename(o)} in {t:.1f}s", file=sys.stderr)
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < _newest(objs):
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed: {r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    print(build(a.force, a.jobs, verbose=True))

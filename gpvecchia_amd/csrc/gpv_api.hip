@@ -1,0 +1,538 @@
+// gpv_api.hip — the C ABI of libgpvecchia_hip.so (include/gpvecchia.h): plan
+// management, host-side re-layout of the R objects into the device plan, and
+// the literal .C()-style drop-ins for the reference's native entry points.
+// There is no CPU compute path in here: without a GPU every entry fails loudly.
+#include "../../include/gpvecchia.h"
+#include "gpv_internal.h"
+
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace gpv;
+
+#define GPV_HIP(expr)                         \
+    do {                                      \
+        hipError_t e_ = (expr);               \
+        if (e_ != hipSuccess) return GPV_ERR_HIP; \
+    } while (0)
+
+namespace {
+
+struct CovSetup {
+    int cov;
+    double sig0, sA, cA, sB, cB;
+};
+
+// covType / covparms -> kernel constants.  matern: covparms = (sigma^2, range, nu)
+// (src/Matern.cpp:24), esqe: (sigma1^2, r1, sigma2^2, r2) (src/Esqe.cpp:17).
+int cov_setup(const char *covType, const double *cp, int ncov, CovSetup &c)
+{
+    if (covType == nullptr || cp == nullptr) return GPV_ERR_BAD_ARG;
+    c = CovSetup{0, 0, 0, 0, 0, 0};
+    if (std::strcmp(covType, "matern") == 0) {
+        if (ncov < 3) return GPV_ERR_BAD_ARG;
+        c.sig0 = cp[0];
+        c.sA = cp[0];
+        if (cp[2] == 0.5) {            // branch chosen by exact == like the reference
+            c.cov = COV_MATERN05;
+            c.cA = 1.0 / cp[1];
+        } else if (cp[2] == 1.5) {
+            c.cov = COV_MATERN15;
+            c.cA = std::sqrt(3.0) / cp[1];
+        } else if (cp[2] == 2.5) {
+            c.cov = COV_MATERN25;
+            c.cA = std::sqrt(5.0) / cp[1];
+        } else {
+            return GPV_ERR_UNSUPPORTED_NU;
+        }
+        return GPV_OK;
+    }
+    if (std::strcmp(covType, "esqe") == 0) {
+        if (ncov < 4) return GPV_ERR_BAD_ARG;
+        c.cov = COV_ESQE;
+        c.sig0 = cp[0] + cp[2];
+        c.sA = cp[0];
+        c.cA = 1.0 / cp[1];
+        c.sB = cp[2];
+        c.cB = 1.0 / (cp[3] * cp[3]);
+        return GPV_OK;
+    }
+    return GPV_ERR_COVTYPE;
+}
+
+template <class F>
+void parallel_for(int64_t n, F f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    int64_t nt = hw ? hw : 4;
+    if (nt > 32) nt = 32;
+    if (n < 65536) nt = 1;
+    if (nt <= 1) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const int64_t chunk = (n + nt - 1) / nt;
+    for (int64_t t = 0; t < nt; ++t) {
+        const int64_t b = t * chunk, e = (b + chunk < n) ? b + chunk : n;
+        if (b >= e) break;
+        th.emplace_back([=] { f(b, e); });
+    }
+    for (auto &t : th) t.join();
+}
+
+inline bool is_missing(int v) { return v == 0 || v == INT_MIN; }
+
+}  // namespace
+
+struct gpv_plan {
+    int device = 0, cus = 0;
+    int64_t Nlocs = 0, row_begin = 0, row_end = 0, rows = 0;
+    int dim = 0, p = 0, P = 0, locs_ld = 0, grid = 1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_locs = nullptr, *d_nuggets = nullptr, *d_z = nullptr, *d_L = nullptr, *d_block = nullptr,
+           *d_sums = nullptr, *d_Z = nullptr, *d_tmp = nullptr, *d_covvals = nullptr;
+    int32_t *d_nn = nullptr;
+    uint8_t *d_cond = nullptr;
+    bool has_z = false, evaluated = false, have_U = false;
+    hipStream_t last_stream = nullptr;
+};
+
+extern "C" {
+
+const char *gpv_status_string(int status)
+{
+    switch (status) {
+        case GPV_OK: return "ok";
+        case GPV_ERR_NO_DEVICE: return "no usable HIP device (libgpvecchia_hip has no CPU fallback)";
+        case GPV_ERR_BAD_ARG: return "bad argument";
+        case GPV_ERR_COVTYPE: return "covariance is not implemented (covType must be \"matern\" or \"esqe\")";
+        case GPV_ERR_UNSUPPORTED_NU: return "Matern smoothness must be 0.5, 1.5 or 2.5 (general-nu Bessel branch not built)";
+        case GPV_ERR_UNSUPPORTED_M: return "m+1 exceeds the widest compiled conditioning-set kernel";
+        case GPV_ERR_HIP: return "HIP runtime error";
+        case GPV_ERR_STATE: return "call order error (no evaluation yet / no data set)";
+        case GPV_ERR_INDEX: return "neighbour index out of range";
+        default: return "unknown status";
+    }
+}
+
+int gpv_version(void) { return 100; }
+
+int gpv_device_count(int *count)
+{
+    if (!count) return GPV_ERR_BAD_ARG;
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) {
+        *count = 0;
+        return GPV_ERR_NO_DEVICE;
+    }
+    *count = c;
+    return c > 0 ? GPV_OK : GPV_ERR_NO_DEVICE;
+}
+
+int gpv_max_p(void) { return max_P(); }
+
+int gpv_plan_destroy(gpv_plan *pl)
+{
+    if (!pl) return GPV_OK;
+    (void)hipSetDevice(pl->device);
+    if (pl->stream) (void)hipStreamSynchronize(pl->stream);
+    void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
+                    pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_nn, pl->d_cond};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    if (pl->ev0) (void)hipEventDestroy(pl->ev0);
+    if (pl->ev1) (void)hipEventDestroy(pl->ev1);
+    if (pl->stream) (void)hipStreamDestroy(pl->stream);
+    delete pl;
+    return GPV_OK;
+}
+
+int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncolNN, const double *locs,
+                    const int *revNN, const int *revCond, int64_t row_begin, int64_t row_end)
+{
+    if (!out) return GPV_ERR_BAD_ARG;
+    *out = nullptr;
+    if (Nlocs <= 0 || dim < 1 || dim > 3 + 1000 || ncolNN < 1 || !revNN) return GPV_ERR_BAD_ARG;
+    if (dim > kMaxDimGeneric) return GPV_ERR_BAD_ARG;
+    if (row_begin < 0 || row_end > Nlocs || row_begin > row_end) return GPV_ERR_BAD_ARG;
+    int ndev = 0;
+    if (gpv_device_count(&ndev) != GPV_OK) return GPV_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return GPV_ERR_NO_DEVICE;
+    const int P = pick_P(ncolNN);
+    if (P == 0) return GPV_ERR_UNSUPPORTED_M;
+    if (hipSetDevice(device) != hipSuccess) return GPV_ERR_NO_DEVICE;
+
+    gpv_plan *pl = new gpv_plan();
+    pl->device = device;
+    pl->Nlocs = Nlocs;
+    pl->row_begin = row_begin;
+    pl->row_end = row_end;
+    pl->rows = row_end - row_begin;
+    pl->dim = dim;
+    pl->p = ncolNN;
+    pl->P = P;
+    pl->locs_ld = (dim == 3) ? 4 : dim;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        delete pl;
+        return GPV_ERR_NO_DEVICE;
+    }
+    pl->cus = prop.multiProcessorCount;
+    pl->grid = suggest_grid(P, pl->rows > 0 ? pl->rows : 1, pl->cus);
+
+    // ---- host re-layout: column-major 1-based R matrices -> row-major, 0-based, right-aligned rows
+    const int64_t rows = pl->rows;
+    std::vector<int32_t> nn((size_t)(rows > 0 ? rows : 1) * P, -1);
+    std::vector<uint8_t> cd((size_t)(rows > 0 ? rows : 1) * P, 1);
+    std::vector<int> err_flag(1, GPV_OK);
+    int *errp = err_flag.data();
+    parallel_for(rows, [=, &nn, &cd](int64_t b, int64_t e) {
+        std::vector<int32_t> tmp(ncolNN);
+        for (int64_t r = b; r < e; ++r) {
+            const int64_t k = row_begin + r;
+            int n0 = 0;
+            for (int j = 0; j < ncolNN; ++j) {            // src/U_NZentries.cpp:44: non-zero entries, compacted, -1
+                const int v = revNN[k + (int64_t)j * Nlocs];
+                if (is_missing(v)) continue;
+                if (v < 1 || (int64_t)v > Nlocs) { *errp = GPV_ERR_INDEX; continue; }
+                tmp[n0++] = v - 1;
+            }
+            int32_t *nr = &nn[(size_t)r * P];
+            uint8_t *cr = &cd[(size_t)r * P];
+            for (int t = 0; t < n0; ++t) {
+                nr[P - n0 + t] = tmp[t];
+                // :47 pairs the compacted indices with the LAST n0 entries of the cond row
+                int c = 1;
+                if (revCond) {
+                    c = revCond[k + (int64_t)(ncolNN - n0 + t) * Nlocs];
+                    if (c == INT_MIN) { *errp = GPV_ERR_BAD_ARG; c = 1; }
+                }
+                cr[P - n0 + t] = (uint8_t)(c != 0);
+            }
+        }
+    });
+    if (err_flag[0] != GPV_OK) {
+        int e = err_flag[0];
+        delete pl;
+        return e;
+    }
+    std::vector<double> lr((size_t)Nlocs * pl->locs_ld, 0.0);
+    if (locs) {
+        const int ld = pl->locs_ld;
+        parallel_for(Nlocs, [=, &lr](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i)
+                for (int t = 0; t < dim; ++t) lr[(size_t)i * ld + t] = locs[i + (int64_t)t * Nlocs];
+        });
+    }
+
+    auto fail = [&](int code) {
+        gpv_plan_destroy(pl);
+        return code;
+    };
+    if (hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipEventCreate(&pl->ev0) != hipSuccess || hipEventCreate(&pl->ev1) != hipSuccess) return fail(GPV_ERR_HIP);
+    const size_t nnb = nn.size() * sizeof(int32_t), cdb = cd.size(), lrb = lr.size() * sizeof(double);
+    if (hipMalloc((void **)&pl->d_nn, nnb) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_cond, cdb) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_locs, lrb) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_nuggets, sizeof(double) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_block, sizeof(double) * kNSums * (size_t)pl->grid) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_sums, sizeof(double) * kNSums) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMemcpy(pl->d_nn, nn.data(), nnb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMemcpy(pl->d_cond, cd.data(), cdb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMemcpy(pl->d_locs, lr.data(), lrb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
+    *out = pl;
+    return GPV_OK;
+}
+
+int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
+{
+    if (!pl || !z_ord) return GPV_ERR_BAD_ARG;
+    GPV_HIP(hipSetDevice(pl->device));
+    if (!pl->d_z) GPV_HIP(hipMalloc((void **)&pl->d_z, sizeof(double) * (size_t)pl->Nlocs));
+    GPV_HIP(hipMemcpy(pl->d_z, z_ord, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyHostToDevice));
+    pl->has_z = true;
+    return GPV_OK;
+}
+
+static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nuggets, int64_t n_nuggets, int flags,
+                          void *stream_v, double *d_sums_out)
+{
+    if ((flags & (GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR)) && !pl->has_z) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    hipStream_t st = stream_v ? (hipStream_t)stream_v : pl->stream;
+    if ((flags & GPV_WANT_U) && !pl->d_L) {
+        GPV_HIP(hipMalloc((void **)&pl->d_L, sizeof(double) * (size_t)(pl->rows > 0 ? pl->rows : 1) * pl->P));
+    }
+    if (cs.cov != COV_DENSE) {
+        if (!nuggets) return GPV_ERR_BAD_ARG;
+        if (n_nuggets == 1) {
+            GPV_HIP(launch_fill(pl->d_nuggets, nuggets[0], pl->Nlocs, st));     // R/createU.R:74
+        } else if (n_nuggets == pl->Nlocs) {
+            GPV_HIP(hipMemcpyAsync(pl->d_nuggets, nuggets, sizeof(double) * (size_t)pl->Nlocs,
+                                   hipMemcpyHostToDevice, st));
+        } else {
+            return GPV_ERR_BAD_ARG;
+        }
+    }
+    SetArgs a;
+    a.locs = pl->d_locs;
+    a.nn = pl->d_nn;
+    a.cond = pl->d_cond;
+    a.nuggets = pl->d_nuggets;
+    a.z = (flags & (GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR)) ? pl->d_z : nullptr;
+    a.covvals = pl->d_covvals;
+    a.Lentries = (flags & GPV_WANT_U) ? pl->d_L : nullptr;
+    a.block_sums = pl->d_block;
+    a.rows = pl->rows;
+    a.nlocs = pl->Nlocs;
+    a.locs_ld = pl->locs_ld;
+    a.dim = pl->dim;
+    a.cov = cs.cov;
+    a.flags = flags;
+    a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
+    GPV_HIP(hipEventRecord(pl->ev0, st));
+    GPV_HIP(launch_sets(pl->P, a, pl->grid, st));
+    GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
+    GPV_HIP(hipEventRecord(pl->ev1, st));
+    pl->evaluated = true;
+    pl->have_U = (flags & GPV_WANT_U) != 0;
+    pl->last_stream = st;
+    return GPV_OK;
+}
+
+int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
+                  int64_t n_nuggets, int flags, void *stream, double *d_sums_out)
+{
+    if (!pl) return GPV_ERR_BAD_ARG;
+    CovSetup cs;
+    const int st = cov_setup(covType, covparms, ncovparms, cs);
+    if (st != GPV_OK) return st;
+    return plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
+}
+
+int gpv_plan_get_sums(gpv_plan *pl, double *sums)
+{
+    if (!pl || !sums) return GPV_ERR_BAD_ARG;
+    if (!pl->evaluated) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    GPV_HIP(hipMemcpyAsync(sums, pl->d_sums, sizeof(double) * kNSums, hipMemcpyDeviceToHost, pl->last_stream));
+    GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    return GPV_OK;
+}
+
+int gpv_plan_get_Lentries(gpv_plan *pl, double *Lentries)
+{
+    if (!pl || !Lentries) return GPV_ERR_BAD_ARG;
+    if (!pl->evaluated || !pl->have_U) return GPV_ERR_STATE;
+    if (pl->rows == 0) return GPV_OK;
+    GPV_HIP(hipSetDevice(pl->device));
+    const size_t bytes = sizeof(double) * (size_t)pl->rows * pl->p;
+    if (!pl->d_tmp) GPV_HIP(hipMalloc((void **)&pl->d_tmp, bytes));
+    GPV_HIP(launch_rows_to_colmajor(pl->d_L, pl->P, pl->rows, pl->p, pl->d_tmp, pl->last_stream));
+    GPV_HIP(hipMemcpyAsync(Lentries, pl->d_tmp, bytes, hipMemcpyDeviceToHost, pl->last_stream));
+    GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    return GPV_OK;
+}
+
+int gpv_plan_get_Zentries(gpv_plan *pl, double *Z)
+{
+    if (!pl || !Z) return GPV_ERR_BAD_ARG;
+    if (!pl->evaluated) return GPV_ERR_STATE;
+    if (pl->rows == 0) return GPV_OK;
+    GPV_HIP(hipSetDevice(pl->device));
+    if (!pl->d_Z) GPV_HIP(hipMalloc((void **)&pl->d_Z, sizeof(double) * 2 * (size_t)pl->rows));
+    GPV_HIP(launch_zentries(pl->d_nuggets + pl->row_begin, pl->rows, pl->d_Z, pl->last_stream));
+    GPV_HIP(hipMemcpyAsync(Z, pl->d_Z, sizeof(double) * 2 * (size_t)pl->rows, hipMemcpyDeviceToHost, pl->last_stream));
+    GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    return GPV_OK;
+}
+
+int gpv_plan_Lentries_device(gpv_plan *pl, double **d_ptr, int64_t *ld)
+{
+    if (!pl || !d_ptr || !ld) return GPV_ERR_BAD_ARG;
+    if (!pl->evaluated || !pl->have_U) return GPV_ERR_STATE;
+    *d_ptr = pl->d_L;
+    *ld = pl->P;
+    return GPV_OK;
+}
+
+int gpv_plan_rows(gpv_plan *pl, int64_t *row_begin, int64_t *row_end)
+{
+    if (!pl || !row_begin || !row_end) return GPV_ERR_BAD_ARG;
+    *row_begin = pl->row_begin;
+    *row_end = pl->row_end;
+    return GPV_OK;
+}
+
+int gpv_plan_last_kernel_ms(gpv_plan *pl, double *ms)
+{
+    if (!pl || !ms) return GPV_ERR_BAD_ARG;
+    if (!pl->evaluated) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    GPV_HIP(hipEventSynchronize(pl->ev1));
+    float f = 0.f;
+    GPV_HIP(hipEventElapsedTime(&f, pl->ev0, pl->ev1));
+    *ms = (double)f;
+    return GPV_OK;
+}
+
+int gpv_loglik_z_from_sums(const double *s, int64_t n, double *loglik)
+{
+    if (!s || !loglik) return GPV_ERR_BAD_ARG;
+    // -1/2 [ sum log(tau+v) + sum (z-mu)^2/(tau+v) + n log 2pi ]  == R/vecchia_likelihood.R:95-96 for cond.yz='z'
+    if (s[6] > 0.0) {
+        *loglik = NAN;     // reference: zero rows in U => log(0) in logdet.num (R/vecchia_likelihood.R:76)
+        return GPV_OK;
+    }
+    *loglik = -0.5 * (s[2] + s[3] + (double)n * std::log(2.0 * M_PI));
+    return GPV_OK;
+}
+
+int gpv_numerator_from_sums(const double *s, double *logdet_num, double *quadform_num)
+{
+    if (!s || !logdet_num || !quadform_num) return GPV_ERR_BAD_ARG;
+    *logdet_num = -2.0 * s[0] + s[5];     // -2 sum log diag(U): latent columns d_k, observed columns 1/sqrt(tau_k)
+    *quadform_num = s[1] + s[4];          // sum z1^2
+    return GPV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// literal drop-ins
+// ---------------------------------------------------------------------------------------
+static int zentries_host(gpv_plan *pl, const double *nuggets_obsord, int64_t n, double *Zentries)
+{
+    if (n <= 0) return GPV_OK;
+    double *d_n = nullptr, *d_Z = nullptr;
+    GPV_HIP(hipMalloc((void **)&d_n, sizeof(double) * (size_t)n));
+    if (hipMalloc((void **)&d_Z, sizeof(double) * 2 * (size_t)n) != hipSuccess) {
+        (void)hipFree(d_n);
+        return GPV_ERR_HIP;
+    }
+    int rc = GPV_OK;
+    if (hipMemcpyAsync(d_n, nuggets_obsord, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, pl->stream) != hipSuccess ||
+        launch_zentries(d_n, n, d_Z, pl->stream) != hipSuccess ||
+        hipMemcpyAsync(Zentries, d_Z, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, pl->stream) != hipSuccess ||
+        hipStreamSynchronize(pl->stream) != hipSuccess)
+        rc = GPV_ERR_HIP;
+    (void)hipFree(d_n);
+    (void)hipFree(d_Z);
+    return rc;
+}
+
+void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const int *dim, const int *ncolNN,
+                     const double *locs, const int *revNNarray, const int *revCondOnLatent, const double *nuggets,
+                     const double *nuggets_obsord, const char **covType, const double *covparms, const int *ncovparms,
+                     double *Lentries, double *Zentries, int *n_failed, int *status)
+{
+    (void)Ncores;
+    int dummy = 0;
+    if (!status) status = &dummy;
+    if (!n || !Nlocs || !dim || !ncolNN || !locs || !revNNarray || !revCondOnLatent || !nuggets || !nuggets_obsord ||
+        !covType || !covparms || !ncovparms || !Lentries || !Zentries) {
+        *status = GPV_ERR_BAD_ARG;
+        return;
+    }
+    CovSetup cs;
+    int rc = cov_setup(*covType, covparms, *ncovparms, cs);   // checked first: src/U_NZentries.cpp:27-29
+    if (rc != GPV_OK) { *status = rc; return; }
+    gpv_plan *pl = nullptr;
+    rc = gpv_plan_create(&pl, 0, *Nlocs, *dim, *ncolNN, locs, revNNarray, revCondOnLatent, 0, *Nlocs);
+    if (rc != GPV_OK) { *status = rc; return; }
+    rc = plan_eval_impl(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
+    if (rc == GPV_OK) rc = gpv_plan_get_Lentries(pl, Lentries);
+    double sums[GPV_NSUMS];
+    if (rc == GPV_OK) rc = gpv_plan_get_sums(pl, sums);
+    if (rc == GPV_OK) rc = zentries_host(pl, nuggets_obsord, *n, Zentries);
+    if (rc == GPV_OK && n_failed) *n_failed = (int)sums[6];
+    gpv_plan_destroy(pl);
+    *status = rc;
+}
+
+void gpv_U_NZentries_mat(const int *Ncores, const int *n, const int *Nlocs, const int *ncolNN, const int *revNNarray,
+                         const double *nuggets_obsord, const double *covVals, double *Lentries, double *Zentries,
+                         int *n_failed, int *status)
+{
+    (void)Ncores;
+    int dummy = 0;
+    if (!status) status = &dummy;
+    if (!n || !Nlocs || !ncolNN || !revNNarray || !nuggets_obsord || !covVals || !Lentries || !Zentries) {
+        *status = GPV_ERR_BAD_ARG;
+        return;
+    }
+    gpv_plan *pl = nullptr;
+    int rc = gpv_plan_create(&pl, 0, *Nlocs, 1, *ncolNN, nullptr, revNNarray, nullptr, 0, *Nlocs);
+    if (rc != GPV_OK) { *status = rc; return; }
+    const size_t bytes = sizeof(double) * (size_t)(*Nlocs) * (size_t)(*Nlocs);
+    if (hipMalloc((void **)&pl->d_covvals, bytes) != hipSuccess ||
+        hipMemcpy(pl->d_covvals, covVals, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        gpv_plan_destroy(pl);
+        *status = GPV_ERR_HIP;
+        return;
+    }
+    CovSetup cs{COV_DENSE, 0, 0, 0, 0, 0};
+    rc = plan_eval_impl(pl, cs, nullptr, 0, GPV_WANT_U, nullptr, nullptr);
+    if (rc == GPV_OK) rc = gpv_plan_get_Lentries(pl, Lentries);
+    double sums[GPV_NSUMS];
+    if (rc == GPV_OK) rc = gpv_plan_get_sums(pl, sums);
+    if (rc == GPV_OK) rc = zentries_host(pl, nuggets_obsord, *n, Zentries);
+    if (rc == GPV_OK && n_failed) *n_failed = (int)sums[6];
+    gpv_plan_destroy(pl);
+    *status = rc;
+}
+
+static void covfun_host(const double *distmat, const int *nelem, const CovSetup &cs, double *covmat, int *status)
+{
+    int ndev = 0;
+    if (gpv_device_count(&ndev) != GPV_OK) { *status = GPV_ERR_NO_DEVICE; return; }
+    const int64_t n = *nelem;
+    if (n <= 0) { *status = GPV_OK; return; }
+    double *d_in = nullptr, *d_out = nullptr;
+    int rc = GPV_OK;
+    if (hipSetDevice(0) != hipSuccess || hipMalloc((void **)&d_in, sizeof(double) * (size_t)n) != hipSuccess) {
+        *status = GPV_ERR_HIP;
+        return;
+    }
+    if (hipMalloc((void **)&d_out, sizeof(double) * (size_t)n) != hipSuccess) {
+        (void)hipFree(d_in);
+        *status = GPV_ERR_HIP;
+        return;
+    }
+    if (hipMemcpy(d_in, distmat, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
+        launch_covfun(d_in, n, cs.cov, cs.sig0, cs.sA, cs.cA, cs.sB, cs.cB, d_out, nullptr) != hipSuccess ||
+        hipMemcpy(covmat, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = GPV_ERR_HIP;
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    *status = rc;
+}
+
+void gpv_MaternFun(const double *distmat, const int *nelem, const double *covparms, double *covmat, int *status)
+{
+    int dummy = 0;
+    if (!status) status = &dummy;
+    if (!distmat || !nelem || !covparms || !covmat) { *status = GPV_ERR_BAD_ARG; return; }
+    CovSetup cs;
+    const int rc = cov_setup("matern", covparms, 3, cs);
+    if (rc != GPV_OK) { *status = rc; return; }
+    covfun_host(distmat, nelem, cs, covmat, status);
+}
+
+void gpv_EsqeFun(const double *distmat, const int *nelem, const double *covparms, double *covmat, int *status)
+{
+    int dummy = 0;
+    if (!status) status = &dummy;
+    if (!distmat || !nelem || !covparms || !covmat) { *status = GPV_ERR_BAD_ARG; return; }
+    CovSetup cs;
+    const int rc = cov_setup("esqe", covparms, 4, cs);
+    if (rc != GPV_OK) { *status = rc; return; }
+    covfun_host(distmat, nelem, cs, covmat, status);
+}
+
+}  // extern "C"

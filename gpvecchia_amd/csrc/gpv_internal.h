@@ -1,0 +1,56 @@
+// gpv_internal.h — declarations shared by the C-ABI layer (gpv_api.hip) and the
+// gfx950 kernels (gpv_sets_kernel.hpp, gpv_aux_kernels.hip).  Not installed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gpv {
+
+// covariance family evaluated inside the conditioning-set kernel
+//   matern branches: src/Matern.cpp:32-42 (nu .5), :43-57 (1.5), :58-71 (2.5); esqe: src/Esqe.cpp:17-39
+enum CovKind : int { COV_MATERN05 = 0, COV_MATERN15 = 1, COV_MATERN25 = 2, COV_ESQE = 3, COV_DENSE = 4 };
+
+constexpr int kNSums = 8;      // GPV_NSUMS
+constexpr int kMaxDimGeneric = 8;
+
+// arguments of one conditioning-set launch (passed by value)
+struct SetArgs {
+    const double *locs;      // [Nlocs][locs_ld] row-major coordinates (device)
+    const int32_t *nn;       // [rows][P] 0-based neighbour index, -1 = missing; valid entries are the LAST n0
+    const uint8_t *cond;     // [rows][P] 1 = condition on latent y, 0 = on observed z
+    const double *nuggets;   // [Nlocs]
+    const double *z;         // [Nlocs] ordered data or nullptr
+    const double *covvals;   // COV_DENSE: [Nlocs][Nlocs] symmetric covariance (U_NZentries_mat) or nullptr
+    double *Lentries;        // [rows][P] row-major, left-aligned, or nullptr
+    double *block_sums;      // [grid][kNSums]
+    int64_t rows;            // conditioning sets in this launch
+    int64_t nlocs;
+    int locs_ld;             // doubles per location in `locs`
+    int dim;                 // spatial dimension (used by the generic-D kernel)
+    int cov;                 // CovKind
+    int flags;               // GPV_WANT_*
+    // covariance constants, precomputed on the host:
+    //   matern: sig0 = sigma^2 (value at distance 0), sA = sigma^2, cA = sqrt(2nu)/range (nu=.5: 1/range)
+    //   esqe:   sig0 = s1+s2, sA = s1, cA = 1/r1, sB = s2, cB = 1/r2^2
+    double sig0, sA, cA, sB, cB;
+};
+
+// launch the conditioning-set kernel compiled for row length P (one of gpv_supported_P) and dimension dim
+hipError_t launch_sets(int P, const SetArgs &a, int grid, hipStream_t stream);
+// smallest compiled P >= p, or 0
+int pick_P(int p);
+int max_P();
+// suggested grid for a P kernel on a device with `cus` compute units
+int suggest_grid(int P, int64_t rows, int cus);
+int sets_per_wave(int P);
+int waves_per_block(int P);
+
+// small helper kernels (gpv_aux_kernels.hip)
+hipError_t launch_reduce_sums(const double *block_sums, int nblocks, double *sums, double *sums_copy, hipStream_t s);
+hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);
+hipError_t launch_zentries(const double *nuggets_obsord, int64_t n, double *Z, hipStream_t s);
+hipError_t launch_rows_to_colmajor(const double *src, int ld, int64_t rows, int cols, double *dst, hipStream_t s);
+hipError_t launch_covfun(const double *dist, int64_t n, int cov, double sig0, double sA, double cA, double sB,
+                         double cB, double *out, hipStream_t s);
+
+}  // namespace gpv

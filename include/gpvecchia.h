@@ -1,0 +1,162 @@
+/*
+ * gpvecchia.h — C ABI of libgpvecchia_hip.so, the MI355X (gfx950) engine for the
+ * GPvecchia U_NZentries hot path and the log-likelihood reductions fed by it.
+ *
+ * Plain C: pointers and sizes only, no R / torch / C++ types.  Every entry
+ * point names the reference interface it replaces (paths relative to the
+ * GPvecchia source tree, v0.1.8).
+ *
+ * Conventions
+ *   - Matrices crossing this boundary are COLUMN-MAJOR (R / Armadillo layout,
+ *     src/RcppExports.cpp:57-63) unless a comment says otherwise.
+ *   - Index arrays are 1-based with 0 (or NA_INTEGER = INT_MIN) for "missing",
+ *     exactly what R/createU.R:146-147 hands to the reference.
+ *   - All functions are blocking host calls unless they take a stream.
+ *   - Status codes: 0 = ok, > 0 = error (gpv_status_string()).  A non-positive-
+ *     definite block is NOT an error (reference: message on Rcerr, zero row,
+ *     src/U_NZentries.cpp:64-66); it is reported through n_failed.
+ *   - The library never falls back to a CPU path: without a usable GPU every
+ *     compute entry returns GPV_ERR_NO_DEVICE.
+ */
+#ifndef GPVECCHIA_H
+#define GPVECCHIA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    GPV_OK = 0,
+    GPV_ERR_NO_DEVICE = 1,      /* no HIP device / HIP runtime error at init        */
+    GPV_ERR_BAD_ARG = 2,        /* null pointer, negative size, bad shard range      */
+    GPV_ERR_COVTYPE = 3,        /* covType not "matern"/"esqe" (src/U_NZentries.cpp:27-29) */
+    GPV_ERR_UNSUPPORTED_NU = 4, /* Matern smoothness outside {0.5,1.5,2.5} (Bessel branch, src/Matern.cpp:72-84, not built yet) */
+    GPV_ERR_UNSUPPORTED_M = 5,  /* m+1 larger than the widest compiled kernel (64)   */
+    GPV_ERR_HIP = 6,            /* HIP runtime failure (alloc, copy, launch)         */
+    GPV_ERR_STATE = 7,          /* call order: result requested before an eval, no data set */
+    GPV_ERR_INDEX = 8           /* neighbour index outside [0, Nlocs]                */
+};
+
+/* gpv_plan_eval flags */
+enum {
+    GPV_WANT_U = 1,        /* materialise Lentries (the U factor entries) in HBM              */
+    GPV_WANT_LOGLIK_Z = 2, /* fused cond.yz='z' log-likelihood sums (needs gpv_plan_set_data) */
+    GPV_WANT_NUMERATOR = 4 /* numerator sums of R/vecchia_likelihood.R:74-76 for any cond.yz  */
+};
+
+/* layout of the 8-double partial-sum vector produced by an eval (summed over the
+ * plan's row shard; one all-reduce(sum) over ranks completes it):
+ *   [0] sum_k log d_k              d_k = diag(U) of the latent column k (= Lentries[k, n0-1])
+ *   [1] sum_k a_k^2                a_k = sum over observed-conditioned neighbours of M_j * z_j   (z1 of :74, latent columns)
+ *   [2] sum_k log(tau_k + v_k)     v_k = 1/d_k^2 conditional variance            (cond.yz='z' only)
+ *   [3] sum_k (z_k - mu_k)^2/(tau_k+v_k), mu_k = -a_k/d_k                       (cond.yz='z' only)
+ *   [4] sum_k z_k^2 / tau_k        (observed columns of z1, :74-75)
+ *   [5] sum_k log tau_k
+ *   [6] number of rows whose block was not positive definite
+ *   [7] number of rows processed
+ */
+#define GPV_NSUMS 8
+
+typedef struct gpv_plan gpv_plan;
+
+const char *gpv_status_string(int status);
+int gpv_version(void);                 /* 100*major + minor */
+int gpv_device_count(int *count);      /* number of visible HIP devices */
+int gpv_max_p(void);                   /* widest supported row length m+1 */
+
+/* -------------------------------------------------------------------------
+ * Literal drop-ins for the reference's native entry points.  Signature shape:
+ * R's .C() convention (every argument a pointer, outputs caller-allocated), so
+ * that an R wrapper needs no compiled glue.
+ *
+ * Replaces: _GPvecchia_U_NZentries  (src/RcppExports.cpp:51-67, arity 9 at :159)
+ *           R stub U_NZentries()    (R/RcppExports.R:22-24), called at R/createU.R:152-154
+ *           body                    src/U_NZentries.cpp:25-118
+ *   Ncores          accepted for signature parity, unused on the GPU
+ *   n               number of observed locations (length of nuggets_obsord)
+ *   Nlocs, dim      rows / cols of locs
+ *   ncolNN          m+1 = columns of revNNarray / revCondOnLatent
+ *   locs            Nlocs x dim double
+ *   revNNarray      Nlocs x ncolNN int, 1-based, 0 or NA_INTEGER = missing
+ *   revCondOnLatent Nlocs x ncolNN int (R logical: 1 TRUE latent, 0 FALSE observed, NA_INTEGER ignored)
+ *   nuggets         Nlocs double (R/createU.R:77), nuggets_obsord n double (R/createU.R:78)
+ *   covType         pointer to a C string, "matern" or "esqe"
+ *   covparms        ncovparms doubles (3 for matern, 4 for esqe)
+ *   Lentries        out, Nlocs x ncolNN double, rows left-aligned and zero padded
+ *   Zentries        out, 2n double  (src/U_NZentries.cpp:111-115)
+ *   n_failed        out, rows left all-zero because the block was not PD
+ *   status          out, GPV_OK or an error code (outputs untouched on error)
+ */
+void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const int *dim, const int *ncolNN,
+                     const double *locs, const int *revNNarray, const int *revCondOnLatent,
+                     const double *nuggets, const double *nuggets_obsord, const char **covType,
+                     const double *covparms, const int *ncovparms, double *Lentries, double *Zentries,
+                     int *n_failed, int *status);
+
+/* Replaces: _GPvecchia_U_NZentries_mat (src/RcppExports.cpp:70-86), R/RcppExports.R:26-28,
+ * body src/U_NZentries.cpp:126-197, call site R/createU.R:149-151.
+ * covVals is the dense Nlocs x Nlocs covariance (column-major); no nugget is added (:144);
+ * locs / revCondOnLatent / nuggets / covparms of the reference signature are unused there
+ * and therefore not part of this ABI. */
+void gpv_U_NZentries_mat(const int *Ncores, const int *n, const int *Nlocs, const int *ncolNN,
+                         const int *revNNarray, const double *nuggets_obsord, const double *covVals,
+                         double *Lentries, double *Zentries, int *n_failed, int *status);
+
+/* Replaces: _GPvecchia_MaternFun / _GPvecchia_EsqeFun (src/RcppExports.cpp, R-visible through
+ * NAMESPACE:3; bodies src/Matern.cpp:24-86, src/Esqe.cpp:17-39).  Elementwise on nelem distances. */
+void gpv_MaternFun(const double *distmat, const int *nelem, const double *covparms, double *covmat, int *status);
+void gpv_EsqeFun(const double *distmat, const int *nelem, const double *covparms, double *covmat, int *status);
+
+/* -------------------------------------------------------------------------
+ * Plan API — the fast path.  A plan is the device-resident image of the
+ * parameter-independent vecchia.approx object (R/vecchia_specify.R:234-235,
+ * U.prep of R/U_sparsity.R:78-79): uploaded and re-laid-out once, evaluated once
+ * per optimiser step (R/vecchia_wrappers.R:72-78 calls vecchia_likelihood each step).
+ *
+ * A plan owns the rows [row_begin, row_end) of the Nlocs conditioning sets
+ * (0-based, half open); locations / nuggets / data are replicated on every
+ * plan.  One plan per GPU; rows shard with no data exchange.
+ */
+int gpv_plan_create(gpv_plan **plan, int device, int64_t Nlocs, int dim, int ncolNN,
+                    const double *locs,            /* Nlocs x dim col-major */
+                    const int *revNNarray,         /* Nlocs x ncolNN col-major, 1-based, 0/NA missing */
+                    const int *revCondOnLatent,    /* Nlocs x ncolNN col-major, R logical */
+                    int64_t row_begin, int64_t row_end);
+int gpv_plan_destroy(gpv_plan *plan);
+
+/* z in ORDERED observation order (zord of R/vecchia_likelihood.R:68), length Nlocs.
+ * Log-likelihood sums assume every location is observed (obs all TRUE, no 'zy'). */
+int gpv_plan_set_data(gpv_plan *plan, const double *z_ord);
+
+/* One evaluation = what createU()+vecchia_likelihood_U() trigger per parameter
+ * value (R/vecchia_likelihood.R:23-26).  nuggets: n_nuggets == 1 (constant,
+ * R/createU.R:74) or == Nlocs (ordered, nuggets.all.ord of R/createU.R:77).
+ * Asynchronous on `stream` (a hipStream_t, NULL = the plan's own stream); results are
+ * valid after the stream is synchronised or after a blocking getter.
+ * If d_sums_out != NULL the GPV_NSUMS partial sums are ALSO written to that
+ * device address (caller-owned, e.g. the buffer an RCCL all-reduce works on). */
+int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms,
+                  const double *nuggets, int64_t n_nuggets, int flags, void *stream, double *d_sums_out);
+
+/* blocking getters (synchronise the eval's stream first) */
+int gpv_plan_get_sums(gpv_plan *plan, double *sums /* GPV_NSUMS */);
+int gpv_plan_get_Lentries(gpv_plan *plan, double *Lentries /* (row_end-row_begin) x ncolNN col-major */);
+int gpv_plan_get_Zentries(gpv_plan *plan, double *Zentries /* 2*(row_end-row_begin) */);
+/* device views for callers that keep U on the GPU: row-major [rows][ld] doubles */
+int gpv_plan_Lentries_device(gpv_plan *plan, double **d_ptr, int64_t *ld);
+int gpv_plan_rows(gpv_plan *plan, int64_t *row_begin, int64_t *row_end);
+/* seconds the last eval's kernels took on the device (hipEvent pair around them) */
+int gpv_plan_last_kernel_ms(gpv_plan *plan, double *ms);
+
+/* cond.yz='z' log-likelihood from the (all-reduced) sums; n = number of observations.
+ * Closed form of R/vecchia_likelihood.R:63-99 when W = U_y U_y^T is diagonal. */
+int gpv_loglik_z_from_sums(const double *sums, int64_t n, double *loglik);
+/* numerator pieces of R/vecchia_likelihood.R:74-76: logdet.num, quadform.num */
+int gpv_numerator_from_sums(const double *sums, double *logdet_num, double *quadform_num);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPVECCHIA_H */
