@@ -299,8 +299,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
     GPV_HIP(hipEventRecord(pl->ev0, st));
     GPV_HIP(launch_sets(pl->P, a, pl->grid, st));
+    GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
-    GPV_HIP(hipEventRecord(pl->ev1, st));
     pl->evaluated = true;
     pl->have_U = (flags & GPV_WANT_U) != 0;
     pl->last_stream = st;

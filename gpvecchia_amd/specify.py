@@ -78,27 +78,32 @@ def _canon_dist(locs, q, cand):
     return np.sqrt(ssq)
 
 
-def find_ordered_nn(locs, m, workers=-1):
+def find_ordered_nn(locs, m, workers=-1, rows=None):
     """Exact ordered nearest neighbours: row j (1-based) lists the min(m+1, j) points of
     locs[1..j] closest to locs[j] (self included) by ascending distance, lower index
     first among equal distances (R's stable order(), R/NN_kdtree.R:79-80).  Same
     definition as GpGp::find_ordered_nn used at R/vecchia_specify.R:159, minus its random
-    jitter.  Returns int32 (n, m+1), 1-based, 0 = NA."""
+    jitter.  Returns int32 (n, m+1), 1-based, 0 = NA.  rows=(a, b) fills only rows a..b-1
+    (a row shard of a multi-GPU plan); the other rows stay 0."""
     from scipy.spatial import cKDTree
     locs = np.ascontiguousarray(locs, dtype=np.float64)
     n = locs.shape[0]
     NN = np.zeros((n, m + 1), dtype=np.int32)
     start = min(n, max(2 * (m + 1), 32))
+    ra, rb = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
     # brute force on the first rows
-    for j in range(start):
+    for j in range(max(0, ra), min(start, rb)):
         d = _canon_dist(locs, np.array([j]), np.arange(j + 1)[None, :])[0]
         o = np.lexsort((np.arange(j + 1), d))[: min(m + 1, j + 1)]
         NN[j, : len(o)] = o + 1
     lo = start
     while lo < n:
         hi = min(n, 2 * lo)
+        if hi <= ra or lo >= rb:
+            lo = hi
+            continue
         tree = cKDTree(locs[:hi])
-        pending = np.arange(lo, hi)
+        pending = np.arange(max(lo, ra), min(hi, rb))
         kk = min(hi, 2 * (m + 1) + 2)
         while pending.size:
             _, ind = tree.query(locs[pending], k=kk, workers=workers)

@@ -147,7 +147,7 @@ int gpv_plan_get_Zentries(gpv_plan *plan, double *Zentries /* 2*(row_end-row_beg
 /* device views for callers that keep U on the GPU: row-major [rows][ld] doubles */
 int gpv_plan_Lentries_device(gpv_plan *plan, double **d_ptr, int64_t *ld);
 int gpv_plan_rows(gpv_plan *plan, int64_t *row_begin, int64_t *row_end);
-/* seconds the last eval's kernels took on the device (hipEvent pair around them) */
+/* milliseconds the last eval's conditioning-set kernel took on the device (hipEvent pair around that launch) */
 int gpv_plan_last_kernel_ms(gpv_plan *plan, double *ms);
 
 /* cond.yz='z' log-likelihood from the (all-reduced) sums; n = number of observations.
