@@ -13,7 +13,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpvecchia_hip.so")
+LIB_PATH = os.environ.get("GPV_LIB") or os.path.join(_HERE, "libgpvecchia_hip.so")   # GPV_LIB: tuning variants only
 NSUMS = 8
 
 GPV_WANT_U = 1

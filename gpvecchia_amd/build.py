@@ -47,14 +47,22 @@ def _compile(args):
     return obj, time.time() - t0
 
 
-def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False, tag: str = "",
+          extra_flags: list[str] | None = None) -> str:
+    """tag/extra_flags build a tuning variant (libgpvecchia_hip<tag>.so, objects under build<tag>/);
+    the default (no tag) is the product library."""
+    global BUILD, LIB
+    if tag:
+        BUILD = os.path.join(CSRC, "build" + tag)
+        LIB = os.path.join(HERE, f"libgpvecchia_hip{tag}.so")
+    extra_flags = list(extra_flags or [])
     os.makedirs(BUILD, exist_ok=True)
     hdrs = [os.path.join(CSRC, f) for f in ("gpv_internal.h", "gpv_sets_kernel.hpp", "gpv_plist.h")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gpvecchia.h"))
     work = []
     for P in plist():
         work.append((os.path.join(CSRC, "gpv_sets_inst.hip"), os.path.join(BUILD, f"sets_p{P}.o"),
-                     [f"-DGPV_INST_P={P}"], hdrs, force))
+                     [f"-DGPV_INST_P={P}"] + extra_flags, hdrs, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), [], hdrs, force))
     work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), [], hdrs, force))
     jobs = jobs or min(8, os.cpu_count() or 1)
@@ -77,5 +85,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--tag", default="")
+    ap.add_argument("--flags", default="", help="extra hipcc flags for the kernel TUs, space separated")
     a = ap.parse_args()
-    print(build(a.force, a.jobs, verbose=True))
+    print(build(a.force, a.jobs, verbose=True, tag=a.tag, extra_flags=a.flags.split()))
