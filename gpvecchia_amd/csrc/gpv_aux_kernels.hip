@@ -56,19 +56,20 @@ hipError_t launch_sets(int P, const SetArgs &a, int grid, hipStream_t stream)
 }
 
 // ---- final reduction: fixed order => run-to-run deterministic ---------------------------
-__global__ void __launch_bounds__(64) gpv_reduce_sums_kernel(const double *block_sums, int nblocks, double *sums,
-                                                             double *sums_copy)
+__global__ void __launch_bounds__(256) gpv_reduce_sums_kernel(const double *block_sums, int nblocks, double *sums,
+                                                              double *sums_copy)
 {
-    // lane = q + 8*part: 8 parts per sum, each a strided serial sum, combined in fixed order
+    // thread = q + 8*part: 32 strided partial sums per quantity (independent loads in flight),
+    // then a fixed-order combine => bitwise reproducible for a given grid
     const int q = threadIdx.x & 7, part = threadIdx.x >> 3;
     double s = 0.0;
-    for (int b = part; b < nblocks; b += 8) s += block_sums[(int64_t)b * kNSums + q];
-    __shared__ double sh[64];
+    for (int b = part; b < nblocks; b += 32) s += block_sums[(int64_t)b * kNSums + q];
+    __shared__ double sh[256];
     sh[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x < kNSums) {
         double t = 0.0;
-        for (int p2 = 0; p2 < 8; ++p2) t += sh[p2 * 8 + threadIdx.x];
+        for (int p2 = 0; p2 < 32; ++p2) t += sh[p2 * 8 + threadIdx.x];
         sums[threadIdx.x] = t;
         if (sums_copy != nullptr) sums_copy[threadIdx.x] = t;
     }
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(64) gpv_reduce_sums_kernel(const double *block
 
 hipError_t launch_reduce_sums(const double *block_sums, int nblocks, double *sums, double *sums_copy, hipStream_t s)
 {
-    hipLaunchKernelGGL(gpv_reduce_sums_kernel, dim3(1), dim3(64), 0, s, block_sums, nblocks, sums, sums_copy);
+    hipLaunchKernelGGL(gpv_reduce_sums_kernel, dim3(1), dim3(256), 0, s, block_sums, nblocks, sums, sums_copy);
     return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@
 //   No MFMA (blocks are tiny), no global atomics, deterministic reductions.
 #pragma once
 #include "gpv_internal.h"
+#include <type_traits>
 
 #ifndef GPV_MINW_SMALL
 #define GPV_MINW_SMALL 4      // launch_bounds waves/SIMD for P <= 32 (=> <= 128 VGPRs)
@@ -51,10 +52,10 @@ __host__ __device__ constexpr int k_min_waves(int P) { return P <= 32 ? GPV_MINW
 template <int P, int D>
 struct SetsLds {
     static constexpr int SPW = 64 / P;
-    static constexpr int TRI = (P * (P - 1) / 2 + 1) & ~1;   // doubles, even => 16 B aligned slices
+    static constexpr int TRI = (P * (P + 1) / 2 + 1) & ~1;   // doubles, even => 16 B aligned slices
     static constexpr int DS = (D == 0) ? kMaxDimGeneric : (D == 3 ? 4 : D);
     static constexpr int COLS = (P + 2) & ~1;     // >= P+1: slot P is a dump slot for idle lanes
-    double tri[SPW][TRI];        // packed strict lower triangle of the covariance block
+    double tri[SPW][TRI];        // packed lower triangle (diagonal included): (hi,lo) at hi(hi+1)/2+lo
     double col[2][SPW][COLS];    // pivot-row exchange, double buffered
     double xy[SPW][P][DS];       // staged coordinates
     double acc[SPW][kNSums];     // per-set running partial sums (ds_add_f64)
@@ -104,6 +105,15 @@ __device__ __forceinline__ double sqrt_pos(double x)
 // exp(-t) for t >= 0 (clamped at 800: exp(-800) == 0 in FP64).  Cody-Waite reduction
 // t = -k ln2 + r, |r| <= ln2/2, degree-11 near-minimax polynomial (Chebyshev interpolant,
 // max relative error 4.2e-18 before rounding), v_ldexp_f64.
+// d = a*b + c with c wave-uniform: forces the 3-operand VOP3 form reading the constant from an
+// SGPR pair (hipcc otherwise emits v_mov_b64 + v_fmac_f64 per Horner step: +9 VALU ops per exp).
+__device__ __forceinline__ double fma_vvs(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+
 __device__ __forceinline__ double exp_neg(double t)
 {
     t = __builtin_fmin(t, 800.0);
@@ -111,16 +121,15 @@ __device__ __forceinline__ double exp_neg(double t)
     const double kd = __builtin_rint(y * 1.4426950408889634);
     double r = __builtin_fma(kd, -6.93147180369123816490e-01, y);
     r = __builtin_fma(kd, -1.90821492927058770002e-10, r);
-    double p = 0x1.af631d0059becp-26;
-    p = __builtin_fma(p, r, 0x1.28b4057f44145p-22);
-    p = __builtin_fma(p, r, 0x1.71ddf5749d126p-19);
-    p = __builtin_fma(p, r, 0x1.a01991ac8730ap-16);
-    p = __builtin_fma(p, r, 0x1.a01a01b14378fp-13);
-    p = __builtin_fma(p, r, 0x1.6c16c187fbe02p-10);
-    p = __builtin_fma(p, r, 0x1.111111110f225p-7);
-    p = __builtin_fma(p, r, 0x1.555555554f0cfp-5);
-    p = __builtin_fma(p, r, 0x1.555555555555ap-3);
-    p = __builtin_fma(p, r, 0x1.0000000000011p-1);
+    double p = fma_vvs(0x1.af631d0059becp-26, r, 0x1.28b4057f44145p-22);
+    p = fma_vvs(p, r, 0x1.71ddf5749d126p-19);
+    p = fma_vvs(p, r, 0x1.a01991ac8730ap-16);
+    p = fma_vvs(p, r, 0x1.a01a01b14378fp-13);
+    p = fma_vvs(p, r, 0x1.6c16c187fbe02p-10);
+    p = fma_vvs(p, r, 0x1.111111110f225p-7);
+    p = fma_vvs(p, r, 0x1.555555554f0cfp-5);
+    p = fma_vvs(p, r, 0x1.555555555555ap-3);
+    p = fma_vvs(p, r, 0x1.0000000000011p-1);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)kd);
@@ -161,12 +170,12 @@ __global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel
     const int sub_raw = lane / P;
     const bool lane_on = sub_raw < SPW;
     const int sub = lane_on ? sub_raw : SPW - 1;
-    const int i = lane_on ? lane - sub_raw * P : 0;
-    const int iw = lane_on ? i : P;      // idle lanes (64 - SPW*P of them) write to the dump slot: no branches in the sweep
+    const int i_const = lane_on ? lane - sub_raw * P : 0;
+    const int iw = lane_on ? i_const : P;      // idle lanes (64 - SPW*P of them) write to the dump slot: no branches in the sweep
     Lds &L = lds_all[wv];
 
     const double sig0 = A.sig0, sA = A.sA, cA = A.cA, sB = A.sB, cB = A.cB;
-    const int tri_i = i * (i - 1) / 2;
+    const int tri_i = i_const * (i_const + 1) / 2;
     const unsigned long long setmask = (P == 64) ? ~0ull : (((1ull << P) - 1ull) << (sub * P));
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
@@ -175,6 +184,10 @@ __global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel
     for (int64_t task = (int64_t)blockIdx.x * W + wv; task < ntasks; task += (int64_t)gridDim.x * W) {
         const int64_t k = task * SPW + sub;
         const bool set_on = lane_on && (k < A.rows);
+        // re-materialise the row index per task: otherwise hipcc hoists all P (i == j) lane masks out of
+        // the task loop (2P SGPRs -> SGPR spills through v_writelane/v_readlane inside the sweep)
+        int i = i_const;
+        asm volatile("" : "+v"(i));
 
         // ---- gather: indices, cond flags, coordinates, nugget, data -------------------
         int idx = -1;
@@ -230,38 +243,43 @@ __global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel
 
         // ---- covariance: every unordered pair once, circulant pairing ------------------
         constexpr int H = P / 2;
+        auto cov_rounds = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll 2
-        for (int s = 1; s <= H; ++s) {
-            int j = i + s;
-            if (j >= P) j -= P;
-            const bool act = lane_on && (((P & 1) == 1) || (s < H) || (i < H));
-            double v;
-            if constexpr (COV == COV_DENSE) {
-                const int jx = L.ix[sub][j];
-                v = (valid && jx >= 0) ? A.covvals[(int64_t)idx * A.nlocs + jx] : 0.0;   // src/U_NZentries.cpp:144
-            } else {
-                double r2 = 0.0;
-                if constexpr (D == 0) {
-                    for (int t = 0; t < A.dim; ++t) {
-                        const double df = L.xy[sub][i][t] - L.xy[sub][j][t];
-                        r2 += df * df;                           // src/dist.cpp:12-14, left to right from 0.0
-                    }
+            for (int s = 1; s <= H; ++s) {
+                const unsigned tj = (unsigned)(i + s);
+                const int j = (int)(tj < tj - P ? tj : tj - P);          // (i + s) mod P via unsigned min
+                const bool act = lane_on && (((P & 1) == 1) || (s < H) || (i < H));
+                double v;
+                if constexpr (COV == COV_DENSE) {
+                    const int jx = L.ix[sub][j];
+                    v = (valid && jx >= 0) ? A.covvals[(int64_t)idx * A.nlocs + jx] : 0.0;   // src/U_NZentries.cpp:144
                 } else {
+                    double r2 = 0.0;
+                    if constexpr (D == 0) {
+                        for (int t = 0; t < A.dim; ++t) {
+                            const double df = L.xy[sub][i][t] - L.xy[sub][j][t];
+                            r2 += df * df;                       // src/dist.cpp:12-14, left to right from 0.0
+                        }
+                    } else {
 #pragma unroll
-                    for (int t = 0; t < D; ++t) {
-                        const double df = xi[t] - L.xy[sub][j][t];
-                        r2 = __builtin_fma(df, df, r2);
+                        for (int t = 0; t < D; ++t) {
+                            const double df = xi[t] - L.xy[sub][j][t];
+                            r2 = __builtin_fma(df, df, r2);
+                        }
+                    }
+                    v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
+                    if constexpr (MASKED) {                      // padded rows/cols -> identity
+                        const bool jvalid = (vmask >> (sub * P + j)) & 1ull;
+                        v = (valid && jvalid) ? v : 0.0;
                     }
                 }
-                v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
-                if (!all_valid) {                                // padded rows/cols -> identity
-                    const bool jvalid = (vmask >> (sub * P + j)) & 1ull;
-                    v = (valid && jvalid) ? v : 0.0;
-                }
+                const int hi = i > j ? i : j, lo = i > j ? j : i;
+                if (act) L.tri[sub][(int)(__umul24(hi, hi + 1) >> 1) + lo] = v;
             }
-            const int hi = i > j ? i : j, lo = i > j ? j : i;
-            if (act) L.tri[sub][(int)(__umul24(hi, hi - 1) >> 1) + lo] = v;
-        }
+        };
+        if (all_valid) cov_rounds(std::false_type{});            // wave-uniform: the common case has no padding
+        else cov_rounds(std::true_type{});
         wave_sync();
 
         // ---- row i of the symmetric block into registers --------------------------------
@@ -271,11 +289,15 @@ __global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel
             if constexpr (COV == COV_DENSE) diag = valid ? A.covvals[(int64_t)idx * A.nlocs + idx] : 1.0;
             else diag = valid ? (sig0 + nugraw * (1.0 - (double)cnd)) : 1.0;   // src/U_NZentries.cpp:47,52
             if (poison) diag = __builtin_nan("");
+            if (lane_on) L.tri[sub][tri_i + i] = diag;
+            wave_sync();
+            // (i,c) lives at tri_i + c for c <= i and at c(c+1)/2 + i above the diagonal: one select per column
+            const double *rowA = &L.tri[sub][tri_i];
+            const double *colB = &L.tri[sub][i];
 #pragma unroll
             for (int c = 0; c < P; ++c) {
-                const int off = (i > c) ? (tri_i + c) : (c * (c - 1) / 2 + i);
-                const double t = L.tri[sub][(i == c) ? 0 : off];
-                a[c] = (i == c) ? diag : t;
+                const double *src = (i >= c) ? (rowA + c) : (colB + c * (c + 1) / 2);
+                a[c] = *src;
             }
         }
         wave_sync();
@@ -287,7 +309,7 @@ __global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel
             double *cb = L.col[j & 1][sub];
             cb[iw] = a[j];                             // column j of the current matrix == pivot row by symmetry
             wave_sync();
-            constexpr int CH = GPV_CHUNK;
+            constexpr int CH = (P <= 32) ? GPV_CHUNK : 4;   // wide rows: keep the burst small, a[] already needs 2P VGPRs
             double t[2][CH];
             // burst 0 of the pivot row is in flight while the reciprocal is computed
 #pragma unroll
