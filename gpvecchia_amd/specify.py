@@ -106,21 +106,28 @@ def find_ordered_nn(locs, m, workers=-1, rows=None):
         pending = np.arange(max(lo, ra), min(hi, rb))
         kk = min(hi, 2 * (m + 1) + 2)
         while pending.size:
-            _, ind = tree.query(locs[pending], k=kk, workers=workers)
+            dq, ind = tree.query(locs[pending], k=kk, workers=workers)
             ind = ind.reshape(len(pending), -1)
+            dq = dq.reshape(len(pending), -1)
             ok = ind <= pending[:, None]
             ok &= ind < hi
             cnt = ok.sum(axis=1)
-            done = (cnt >= m + 2) | (kk >= hi)      # one spare candidate guards the boundary against ulp ties
+            # exact under ties: the (m+1)-th eligible distance must lie strictly inside the queried ball,
+            # otherwise an equidistant point with a lower index may have been cut off by the k-NN query
+            dm = np.sort(np.where(ok, dq, np.inf), axis=1)[:, min(m, kk - 1)]
+            done = ((cnt >= m + 1) & (dq[:, -1] > dm * (1 + 1e-9))) | (kk >= hi)
             if done.any():
-                rows = np.where(done)[0]
-                q = pending[rows]
-                cand = np.where(ok[rows], ind[rows], q[:, None])       # masked-out slots -> self (deduplicated by key)
+                sel = np.where(done)[0]
+                q = pending[sel]
+                cand = np.where(ok[sel], ind[sel], q[:, None])         # masked-out slots -> self (deduplicated by key)
                 d = _canon_dist(locs, q, cand)
-                d = np.where(ok[rows], d, np.inf)
-                idxkey = np.where(ok[rows], cand, np.iinfo(np.int64).max)
+                d = np.where(ok[sel], d, np.inf)
+                idxkey = np.where(ok[sel], cand, np.iinfo(np.int64).max)
                 o = np.lexsort((idxkey, d), axis=1)[:, : m + 1]
                 NN[q] = np.take_along_axis(cand, o, axis=1).astype(np.int32) + 1
+                if kk >= hi:                                             # whole prefix queried: drop the padding
+                    pad = np.take_along_axis(d, o, axis=1) == np.inf
+                    NN[q] = np.where(pad, 0, NN[q])
             pending = pending[~done]
             kk = min(hi, kk * 2)
         lo = hi

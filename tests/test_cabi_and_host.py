@@ -1,0 +1,186 @@
+"""CPU tests: the C-ABI library loads and exports every symbol include/gpvecchia.h declares
+(no compute without a GPU), error behaviour at the boundary, and the host-side mirror of
+the R setup code against the oracle's literal restatement."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_all_exported():
+    from gpvecchia_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "gpvecchia.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(gpv_[A-Za-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS)
+    L = _lib.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    out = os.popen(f"nm -D --defined-only {_lib.LIB_PATH}").read()
+    for name in declared:
+        assert re.search(rf"\bT {name}\b", out), name
+
+
+def test_library_contains_gfx950_code_object():
+    from gpvecchia_amd import _lib
+    _lib.lib()
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gpv_sets_kernel" in blob
+
+
+def test_status_strings_and_pure_host_entry_points():
+    import gpvecchia_amd as G
+    from gpvecchia_amd import _lib
+    L = _lib.lib()
+    assert L.gpv_version() >= 100
+    assert L.gpv_max_p() == 64
+    for code in range(0, 9):
+        assert len(L.gpv_status_string(code)) > 0
+    # gpv_loglik_z_from_sums / gpv_numerator_from_sums are host arithmetic: testable without a GPU
+    s = np.array([1.5, 2.0, 10.0, 7.0, 3.0, -4.0, 0.0, 5.0])
+    assert G.loglik_z_from_sums(s, 5) == pytest.approx(-0.5 * (10.0 + 7.0 + 5 * np.log(2 * np.pi)), rel=1e-15)
+    ld, qf = G.numerator_from_sums(s)
+    assert ld == pytest.approx(-2 * 1.5 - 4.0) and qf == pytest.approx(5.0)
+    s[6] = 1
+    assert np.isnan(G.loglik_z_from_sums(s, 5))
+
+
+@pytest.mark.skipif(__import__("gpvecchia_amd").device_count() > 0, reason="only meaningful without a GPU")
+def test_no_cpu_fallback_without_gpu(kat):
+    import gpvecchia_amd as G
+    va = G.vecchia_specify(kat["locs"], kat["m"], ordering="none", cond_yz="z")
+    with pytest.raises(G.GpvError) as e:
+        G.vecchia_likelihood(kat["z"], va, kat["covparms"], kat["nugget"])
+    assert e.value.status == 1
+    with pytest.raises(G.GpvError):
+        G.MaternFun(np.zeros(3), [1, 1, .5])
+
+
+def test_argument_errors_before_any_device_work():
+    import gpvecchia_amd as G
+    from gpvecchia_amd import _lib
+    L = _lib.lib()
+    status = ctypes.c_int(-1)
+    L.gpv_U_NZentries(None, None, None, None, None, None, None, None, None, None, None, None, None, None, None, None,
+                      ctypes.byref(status))
+    assert status.value == 2
+    # covType is validated before the device is touched (src/U_NZentries.cpp:27-29)
+    locs = np.zeros((2, 2)); nn = np.array([[0, 1], [1, 2]]); cd = np.array([[0, 1], [1, 1]])
+    with pytest.raises(G.GpvError) as e:
+        G.U_NZentries(1, 2, locs, nn, cd, np.ones(2), np.ones(2), "gauss", [1, 1, .5])
+    assert e.value.status == 3
+    with pytest.raises(G.GpvError) as e:
+        G.U_NZentries(1, 2, locs, nn, cd, np.ones(2), np.ones(2), "matern", [1, 1, .7])
+    assert e.value.status == 4
+
+
+# ---------------------------------------------------------------------------------------
+# host mirror vs the oracle's literal restatement of the R code
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_find_ordered_nn_is_exact(d):
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    rng = np.random.default_rng(d)
+    locs = rng.random((900, d))
+    for m in (1, 5, 30):
+        a = S.find_ordered_nn(locs, m)
+        b = np.nan_to_num(R.findOrderedNN(locs, m)).astype(np.int32)
+        assert np.array_equal(a, b)            # bit-exact neighbour arrays
+
+
+def test_find_ordered_nn_ties_and_duplicates():
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    g = np.stack(np.meshgrid(np.arange(12.0), np.arange(9.0)), -1).reshape(-1, 2)     # regular grid: many exact ties
+    g = np.vstack([g, g[:7]])                                                        # exact duplicates
+    a = S.find_ordered_nn(g, 8)
+    b = np.nan_to_num(R.findOrderedNN(g, 8)).astype(np.int32)
+    assert np.array_equal(a, b)                # lower index wins ties, like R's stable order()
+    sh = S.find_ordered_nn(g, 8, rows=(40, 77))
+    assert np.array_equal(sh[40:77], a[40:77]) and not sh[:40].any() and not sh[77:].any()
+
+
+@pytest.mark.parametrize("ordering", ["none", "coord", "maxmin"])
+@pytest.mark.parametrize("cond", ["z", "y", "SGV"])
+def test_vecchia_specify_matches_oracle(ordering, cond):
+    import gpvecchia_amd as G
+    from oracle import r_side as R
+    rng = np.random.default_rng(4)
+    locs = rng.random((300, 2))
+    va = G.vecchia_specify(locs, 7, ordering=ordering, cond_yz=cond)
+    vb = R.vecchia_specify(locs, 7, ordering=ordering, cond_yz=cond)
+    assert np.array_equal(va["ord"], vb["ord"])
+    pa, pb = va["U_prep"], vb["U_prep"]
+    assert np.array_equal(pa["revNNarray"], np.nan_to_num(pb["revNNarray"]).astype(np.int32))
+    assert np.array_equal(pa["revCond"], np.nan_to_num(pb["revCond"], nan=-1).astype(np.int8))
+    for k in ("rowpointers", "colindices", "y_ind"):
+        assert np.array_equal(pa[k], pb[k])
+    assert pa["size"] == pb["size"] == 600
+
+
+def test_vecchia_specify_edge_cases():
+    import gpvecchia_amd as G
+    locs = np.random.default_rng(0).random((20, 2))
+    with pytest.warns(UserWarning):
+        va = G.vecchia_specify(locs, 50, ordering="none", cond_yz="z")      # m > n -> m = n-1
+    assert va["U_prep"]["revNNarray"].shape == (20, 20)
+    v0 = G.vecchia_specify(locs, 0)                                          # independent case
+    assert v0["cond_yz"] == "false" and v0["U_prep"]["revNNarray"].shape == (20, 2)
+    assert np.array_equal(v0["U_prep"]["revNNarray"][:, 1], np.arange(1, 21))
+    with pytest.raises(ValueError):
+        G.vecchia_specify(locs, 3, ordering="spiral")
+    with pytest.raises(ValueError):
+        G.vecchia_specify(locs, 3, cond_yz="q")
+    with pytest.warns(UserWarning):
+        assert G.vecchia_specify(np.zeros(5), 2) is None                     # "Locations must be in matrix form"
+    v1 = G.vecchia_specify(np.sort(np.random.default_rng(1).random((30, 1)), axis=0)[::-1].copy(), 3)
+    assert np.array_equal(v1["ord"], np.arange(30, 0, -1))                   # 1-D default ordering = 'coord'
+
+
+def test_orderings():
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    locs = np.random.default_rng(9).random((150, 2))
+    assert np.array_equal(S.order_maxmin_exact(locs), R.order_maxmin_exact(locs))
+    assert np.array_equal(S.order_coordinate(locs), R.order_coordinate(locs))
+    o = S.order_maxmin_exact(locs)
+    assert sorted(o.tolist()) == list(range(1, 151))
+    # max-min property: each point maximises the distance to the already chosen ones
+    d = R.rdist(locs)
+    for t in (1, 5, 40):
+        chosen = o[:t] - 1
+        mind = d[:, chosen].min(axis=1)
+        mind[chosen] = -1
+        assert mind[o[t] - 1] == mind.max()
+    mo = S.order_middleout(locs)
+    assert np.array_equal(S.order_outsidein(locs), mo[::-1])
+
+
+def test_removeNAs_semantics():
+    from gpvecchia_amd.api import _removeNAs
+    z = np.array([1.0, np.nan, 3.0, 5.0])
+    z2, nug = _removeNAs(z, 0.1)
+    assert z2[1] == 3.0 and nug[1] == np.var([1.0, 3.0, 5.0], ddof=1) * 1e8        # R/vecchia_likelihood.R:55-56
+    assert np.array_equal(nug[[0, 2, 3]], [0.1, 0.1, 0.1])
+    z3, n3 = _removeNAs(np.array([1.0, 2.0]), 0.3)
+    assert np.array_equal(z3, [1.0, 2.0]) and n3.tolist() == [0.3]
+
+
+def test_host_likelihood_U_matches_oracle():
+    # the host-side (sparse) vecchia_likelihood_U / U2V of the mirror vs the oracle's dense restatement
+    import scipy.sparse as sp
+    import gpvecchia_amd as G
+    from oracle import r_side as R
+    rng = np.random.default_rng(2)
+    locs = rng.random((200, 2)); z = rng.standard_normal(200)
+    for cond in ("SGV", "y", "z"):
+        vb = R.vecchia_specify(locs, 6, ordering="maxmin", cond_yz=cond)
+        Uo = R.createU(vb, [1.0, 0.2, 1.5], 0.1)
+        U_obj = dict(U=sp.csc_matrix(Uo["U"]), latent=Uo["latent"], ord_z=Uo["ord_z"])
+        assert G.vecchia_likelihood_U(z, U_obj) == pytest.approx(R.vecchia_likelihood_U(z, Uo), rel=1e-11)
