@@ -54,7 +54,10 @@ struct SetsLds {
     static constexpr int SPW = 64 / P;
     static constexpr int TRI = (P * (P + 1) / 2 + 1) & ~1;   // doubles, even => 16 B aligned slices
     static constexpr int DS = (D == 0) ? kMaxDimGeneric : (D == 3 ? 4 : D);
-    static constexpr int COLS = (P + 2) & ~1;     // >= P+1: slot P is a dump slot for idle lanes
+    // >= P+1 (slot P is a dump slot for idle lanes) and == 2 (mod 32): consecutive sets start 16 B apart
+    // modulo the 256-B bank row, so the broadcast ds_read_b128 of lanes that straddle two sets do not
+    // collide (with a 256-B-aligned stride every pivot-row read paid a 2-way conflict: +25 % LDS cycles)
+    static constexpr int COLS = ((P + 1 + 29) / 32) * 32 + 2;
     double tri[SPW][TRI];        // packed lower triangle (diagonal included): (hi,lo) at hi(hi+1)/2+lo
     double col[2][SPW][COLS];    // pivot-row exchange, double buffered
     double xy[SPW][P][DS];       // staged coordinates
