@@ -184,7 +184,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
         return GPV_ERR_NO_DEVICE;
     }
     pl->cus = prop.multiProcessorCount;
-    pl->grid = suggest_grid(P, pl->rows > 0 ? pl->rows : 1, pl->cus);
+    pl->grid = 1;
 
     // ---- host re-layout: column-major 1-based R matrices -> row-major, 0-based, right-aligned rows
     const int64_t rows = pl->rows;
@@ -242,7 +242,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     if (hipMalloc((void **)&pl->d_cond, cdb) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMalloc((void **)&pl->d_locs, lrb) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMalloc((void **)&pl->d_nuggets, sizeof(double) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_block, sizeof(double) * kNSums * (size_t)pl->grid) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_block, sizeof(double) * kNSums * (size_t)kMaxGrid) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMalloc((void **)&pl->d_sums, sizeof(double) * kNSums) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMemcpy(pl->d_nn, nn.data(), nnb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMemcpy(pl->d_cond, cd.data(), cdb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
@@ -298,7 +298,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.flags = flags;
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
     GPV_HIP(hipEventRecord(pl->ev0, st));
-    GPV_HIP(launch_sets(pl->P, a, pl->grid, st));
+    GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
     pl->evaluated = true;

@@ -7,7 +7,7 @@
 namespace gpv {
 
 // ---- dispatch over the compiled row lengths ------------------------------------------
-#define GPV_DECL(P) hipError_t launch_sets_p##P(const SetArgs &, int, hipStream_t);
+#define GPV_DECL(P) hipError_t launch_sets_p##P(const SetArgs &, int, int *, hipStream_t);
 GPV_P_LIST(GPV_DECL)
 #undef GPV_DECL
 
@@ -29,25 +29,12 @@ int max_P()
     for (int v : kPList) m = v > m ? v : m;
     return m;
 }
-int sets_per_wave(int P) { return k_spw(P); }
-int waves_per_block(int P) { return k_wpb(P); }
-
-int suggest_grid(int P, int64_t rows, int cus)
-{
-    const int64_t tasks = (rows + k_spw(P) - 1) / k_spw(P);
-    const int64_t blocks_needed = (tasks + k_wpb(P) - 1) / k_wpb(P);
-    // resident blocks per CU: 4 x 256-thread blocks (P <= 32) or 8 x 64-thread blocks; x2 waves of work per slot
-    const int64_t cap = (int64_t)cus * (P <= 32 ? 4 : 8) * 2;
-    int64_t g = blocks_needed < cap ? blocks_needed : cap;
-    return (int)(g < 1 ? 1 : g);
-}
-
-hipError_t launch_sets(int P, const SetArgs &a, int grid, hipStream_t stream)
+hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
 {
     switch (P) {
 #define GPV_CASE(P) \
     case P:         \
-        return launch_sets_p##P(a, grid, stream);
+        return launch_sets_p##P(a, cus, grid_out, stream);
         GPV_P_LIST(GPV_CASE)
 #undef GPV_CASE
         default:

@@ -12,6 +12,7 @@ enum CovKind : int { COV_MATERN05 = 0, COV_MATERN15 = 1, COV_MATERN25 = 2, COV_E
 
 constexpr int kNSums = 8;      // GPV_NSUMS
 constexpr int kMaxDimGeneric = 8;
+constexpr int kMaxGrid = 16384;   // upper bound of the conditioning-set grid (block_sums is sized for it)
 
 // arguments of one conditioning-set launch (passed by value)
 struct SetArgs {
@@ -35,15 +36,12 @@ struct SetArgs {
     double sig0, sA, cA, sB, cB;
 };
 
-// launch the conditioning-set kernel compiled for row length P (one of gpv_supported_P) and dimension dim
-hipError_t launch_sets(int P, const SetArgs &a, int grid, hipStream_t stream);
+// launch the conditioning-set kernel compiled for row length P (one of gpv_plist.h); the grid is chosen from
+// the instantiation's LDS footprint and the device's CU count and returned through grid_out (<= kMaxGrid)
+hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStream_t stream);
 // smallest compiled P >= p, or 0
 int pick_P(int p);
 int max_P();
-// suggested grid for a P kernel on a device with `cus` compute units
-int suggest_grid(int P, int64_t rows, int cus);
-int sets_per_wave(int P);
-int waves_per_block(int P);
 
 // small helper kernels (gpv_aux_kernels.hip)
 hipError_t launch_reduce_sums(const double *block_sums, int nblocks, double *sums, double *sums_copy, hipStream_t s);

@@ -6,8 +6,8 @@
 #define GPV_CAT2(a, b) a##b
 #define GPV_CAT(a, b) GPV_CAT2(a, b)
 namespace gpv {
-hipError_t GPV_CAT(launch_sets_p, GPV_INST_P)(const SetArgs &a, int grid, hipStream_t stream)
+hipError_t GPV_CAT(launch_sets_p, GPV_INST_P)(const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
 {
-    return launch_sets_P<GPV_INST_P>(a, grid, stream);
+    return launch_sets_P<GPV_INST_P>(a, cus, grid_out, stream);
 }
 }  // namespace gpv

@@ -6,8 +6,10 @@
 // R^T R = S and x = R^{-1} e_last, stored left-aligned in Lentries[k,].
 //
 // How (not a translation of the reference):
-//   * one wavefront handles SPW = floor(64/P) conditioning sets at once, lane
-//     (sub, i) owns ROW i of set `sub` of the symmetric block in 2P VGPRs;
+//   * one wavefront handles SPW = floor(64/LPS) conditioning sets at once; a set is spread
+//     over LPS lanes and lane (sub, i) owns the rows i, i+LPS, .. (RPL rows per lane: 2 for
+//     P <= 32, 1 above) of the symmetric block in 2*RPL*P VGPRs.  Two rows per lane halve
+//     the LDS broadcast volume per FMA and the per-pivot overhead per set;
 //   * neighbour indices / cond flags are read as one contiguous segment per set,
 //     coordinates gathered with one 8*D-byte load per lane and staged in LDS;
 //   * the P(P-1)/2 distinct covariances are evaluated once each with a circulant
@@ -23,6 +25,9 @@
 //     with broadcast reads that are software-pipelined in chunks against the FMAs,
 //     and the pivots are exactly the Schur complements d_j^2 whose positivity
 //     decides "Cholesky failed" in the reference (:60-66);
+//   * a spare row slot (P odd, or a spare lane) carries the DATA as one more row of the
+//     sweep: after the last pivot it holds -mu_k = -sum_j b_j z_j, the conditional mean needed
+//     by the likelihood, at zero extra instructions (no cross-lane reduction);
 //   * optional fused epilogue: the log-likelihood partial sums of
 //     R/vecchia_likelihood.R:74-76 (and the closed form for cond.yz='z'), so a
 //     likelihood evaluation never writes the 248 MB factor to HBM.
@@ -32,7 +37,7 @@
 #include <type_traits>
 
 #ifndef GPV_MINW_SMALL
-#define GPV_MINW_SMALL 4      // launch_bounds waves/SIMD for P <= 32 (=> <= 128 VGPRs)
+#define GPV_MINW_SMALL 2      // launch_bounds waves/SIMD for P <= 32 (2 rows per lane => up to 256 VGPRs)
 #endif
 #ifndef GPV_MINW_LARGE
 #define GPV_MINW_LARGE 2      // for P > 32 (=> <= 256 VGPRs)
@@ -43,27 +48,59 @@
 
 namespace gpv {
 
-__host__ __device__ constexpr int k_spw(int P) { return 64 / P; }
-// waves per workgroup: LDS per wave grows with P^2, keep >= 8 waves/CU resident
-__host__ __device__ constexpr int k_wpb(int P) { return P <= 32 ? 4 : 1; }
-// register budget: launch_bounds 2nd argument = waves per SIMD the allocator must allow
-__host__ __device__ constexpr int k_min_waves(int P) { return P <= 32 ? GPV_MINW_SMALL : GPV_MINW_LARGE; }
+// geometry of one conditioning set inside a wavefront
+template <int P>
+struct Geo {
+    static constexpr int RPL = (P >= 24 && P <= 32) ? 2 : 1;                    // rows per lane (measured: pays from P ~ 24)
+    static constexpr int LPS0 = (P + RPL - 1) / RPL;                            // lanes per set, minimal
+    // one more lane per set when it costs no set per wave: guarantees a spare row slot for the data row
+    static constexpr int LPS = (LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0;
+    static constexpr int SLOTS = LPS * RPL;                                     // row slots per set (>= P)
+    static constexpr bool ZROW = SLOTS > P;                                     // slot P carries the data row
+    static constexpr int SPW = 64 / LPS;                                        // sets per wave
+    static constexpr int MINW = (P <= 32) ? GPV_MINW_SMALL : GPV_MINW_LARGE;    // launch_bounds waves/SIMD
+};
 
-template <int P, int D>
+__host__ __device__ constexpr int k_lps(int P)
+{
+    const int rpl = (P >= 24 && P <= 32) ? 2 : 1;
+    const int l0 = (P + rpl - 1) / rpl;
+    return (l0 * rpl == P && l0 < 64 && 64 / (l0 + 1) == 64 / l0) ? l0 + 1 : l0;
+}
+__host__ __device__ constexpr int k_spw(int P) { return 64 / k_lps(P); }
+
+template <int P, int D, int COV>
 struct SetsLds {
-    static constexpr int SPW = 64 / P;
+    using G = Geo<P>;
+    static constexpr int SPW = G::SPW;
     static constexpr int TRI = (P * (P + 1) / 2 + 1) & ~1;   // doubles, even => 16 B aligned slices
     static constexpr int DS = (D == 0) ? kMaxDimGeneric : (D == 3 ? 4 : D);
-    // >= P+1 (slot P is a dump slot for idle lanes) and == 2 (mod 32): consecutive sets start 16 B apart
-    // modulo the 256-B bank row, so the broadcast ds_read_b128 of lanes that straddle two sets do not
-    // collide (with a 256-B-aligned stride every pivot-row read paid a 2-way conflict: +25 % LDS cycles)
-    static constexpr int COLS = ((P + 1 + 29) / 32) * 32 + 2;
+    // >= SLOTS+1 (the last slot is a dump slot for idle lanes), even, and never a multiple of the 256-B bank
+    // row: consecutive sets then start in different banks, so broadcast ds_read_b128 of lanes that straddle
+    // two sets do not collide (with a 256-B-aligned stride every pivot-row read paid a 2-way conflict)
+    static constexpr int COLS0 = (G::SLOTS + 2) & ~1;
+    static constexpr int COLS = ((COLS0 * 8) % 256 == 0) ? COLS0 + 2 : COLS0;
     double tri[SPW][TRI];        // packed lower triangle (diagonal included): (hi,lo) at hi(hi+1)/2+lo
-    double col[2][SPW][COLS];    // pivot-row exchange, double buffered
+    double col[2][SPW][COLS];    // pivot-row exchange, double buffered; col[1] doubles as the data-row staging
     double xy[SPW][P][DS];       // staged coordinates
-    double acc[SPW][kNSums];     // per-set running partial sums (ds_add_f64)
-    int ix[SPW][COLS];           // staged neighbour indices (dense-covariance variant)
+    static constexpr bool NEEDZERO = G::SLOTS > P + (G::ZROW ? 1 : 0);
+    double zero[NEEDZERO ? COLS : 2];   // source of the padding rows beyond the data row
+    double acc[SPW][kNSums];     // per-set running partial sums
+    int ix[COV == COV_DENSE ? SPW : 1][COV == COV_DENSE ? COLS : 2];   // staged neighbour indices (dense-covariance variant)
 };
+
+// waves per workgroup: 4 when two 4-wave workgroups fit the 160 KiB of LDS of a CU, else single-wave workgroups
+template <int P, int D, int COV>
+constexpr int wpb() { return (sizeof(SetsLds<P, D, COV>) * 8 <= 163840) ? 4 : 1; }
+// resident workgroups per CU (LDS-limited, at most 2 waves per SIMD are needed)
+template <int P, int D, int COV>
+constexpr int blocks_per_cu()
+{
+    const int w = wpb<P, D, COV>();
+    const int by_lds = (int)(163840 / (sizeof(SetsLds<P, D, COV>) * w));
+    const int cap = 8 / w;                          // 2 waves per SIMD
+    return by_lds < cap ? (by_lds < 1 ? 1 : by_lds) : cap;
+}
 
 // Lanes of one wavefront exchange data through LDS.  The hardware executes a wave's LDS
 // instructions in order, so no s_barrier is needed; this only pins the compiler's ordering.
@@ -103,6 +140,18 @@ __device__ __forceinline__ double sqrt_pos(double x)
     h = __builtin_fma(h, r, h);
     const double d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
+}
+
+// 1/sqrt(x), x > 0 normal: v_rsq_f64 seed + two Newton steps on y (error ~1 ulp)
+__device__ __forceinline__ double rsqrt_pos(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    double e = __builtin_fma(-hx * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-hx * y, y, 0.5);
+    y = __builtin_fma(y, e, y);
+    return y;
 }
 
 // exp(-t) for t >= 0 (clamped at 800: exp(-800) == 0 in FP64).  Cody-Waite reduction
@@ -161,235 +210,320 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 }
 
 template <int P, int D, int COV>
-__global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel(const SetArgs A)
+__global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_sets_kernel(const SetArgs A)
 {
-    constexpr int SPW = 64 / P;
-    constexpr int W = k_wpb(P);
-    using Lds = SetsLds<P, D>;
+    using G = Geo<P>;
+    constexpr int RPL = G::RPL, LPS = G::LPS, SPW = G::SPW, W = wpb<P, D, COV>();
+    constexpr bool ZROW = G::ZROW;
+    using Lds = SetsLds<P, D, COV>;
+    constexpr int COLS = Lds::COLS;
     __shared__ Lds lds_all[W];
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    const int sub_raw = lane / P;
+    const int sub_raw = lane / LPS;
     const bool lane_on = sub_raw < SPW;
     const int sub = lane_on ? sub_raw : SPW - 1;
-    const int i_const = lane_on ? lane - sub_raw * P : 0;
-    const int iw = lane_on ? i_const : P;      // idle lanes (64 - SPW*P of them) write to the dump slot: no branches in the sweep
+    const int i_const = lane_on ? lane - sub_raw * LPS : 0;
     Lds &L = lds_all[wv];
 
     const double sig0 = A.sig0, sA = A.sA, cA = A.cA, sB = A.sB, cB = A.cB;
-    const int tri_i = i_const * (i_const + 1) / 2;
-    const unsigned long long setmask = (P == 64) ? ~0ull : (((1ull << P) - 1ull) << (sub * P));
+    const unsigned long long setmask = (LPS == 64) ? ~0ull : (((1ull << LPS) - 1ull) << (sub * LPS));
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
+    for (int q = lane; q < (Lds::NEEDZERO ? COLS : 2); q += 64) L.zero[q] = 0.0;
 
     const int64_t ntasks = (A.rows + SPW - 1) / SPW;
     for (int64_t task = (int64_t)blockIdx.x * W + wv; task < ntasks; task += (int64_t)gridDim.x * W) {
         const int64_t k = task * SPW + sub;
         const bool set_on = lane_on && (k < A.rows);
-        // re-materialise the row index per task: otherwise hipcc hoists all P (i == j) lane masks out of
-        // the task loop (2P SGPRs -> SGPR spills through v_writelane/v_readlane inside the sweep)
+        // re-materialise the lane's row index per task: otherwise hipcc hoists all P (row == j) lane masks
+        // out of the task loop (2P SGPRs -> SGPR spills through v_writelane/v_readlane inside the sweep)
         int i = i_const;
         asm volatile("" : "+v"(i));
 
         // ---- gather: indices, cond flags, coordinates, nugget, data -------------------
-        int idx = -1;
-        int cnd = 1;
-        if (set_on) {
-            idx = A.nn[k * P + i];
-            cnd = A.cond[k * P + i];
-        }
-        const bool valid = idx >= 0;
-        double xi[(D == 0) ? 1 : D];
-        double nugraw = 0.0, zi = 0.0;
-        bool poison = false;             // NaN coordinate => NaN block => "Cholesky failed" like the reference
-        if (valid && COV != COV_DENSE) {
-            const double *lp = A.locs + (int64_t)idx * A.locs_ld;
-            if constexpr (D == 0) {
-                for (int t = 0; t < A.dim; ++t) {
-                    const double c = lp[t];
-                    poison = poison | (c != c);
-                    L.xy[sub][i][t] = c;
-                }
-            } else if constexpr (D == 2) {
-                const double2 v2 = *reinterpret_cast<const double2 *>(lp);
-                xi[0] = v2.x; xi[1] = v2.y;
-            } else if constexpr (D == 3) {
-                const double2 v2 = *reinterpret_cast<const double2 *>(lp);
-                xi[0] = v2.x; xi[1] = v2.y; xi[2] = lp[2];
-            } else {
+        int row[RPL], idx[RPL], cnd[RPL], wslot[RPL];
+        bool valid[RPL], poison[RPL];
+        double xi[RPL][(D == 0) ? 1 : D];
+        double nugraw[RPL], zi[RPL];
+        unsigned long long vmask[RPL];
 #pragma unroll
-                for (int t = 0; t < D; ++t) xi[t] = lp[t];
+        for (int q = 0; q < RPL; ++q) {
+            row[q] = i + q * LPS;
+            wslot[q] = lane_on ? row[q] : COLS - 1;          // idle lanes write to the dump slot: no branches in the sweep
+            idx[q] = -1;
+            cnd[q] = 1;
+            if (set_on && row[q] < P) {
+                idx[q] = A.nn[k * P + row[q]];
+                cnd[q] = A.cond[k * P + row[q]];
             }
-            nugraw = A.nuggets[idx];
-        } else {
+            valid[q] = idx[q] >= 0;
+            poison[q] = false;                                // NaN coordinate => NaN block => "Cholesky failed"
+            nugraw[q] = 0.0;
+            zi[q] = 0.0;
+            if (valid[q] && COV != COV_DENSE) {
+                const double *lp = A.locs + (int64_t)idx[q] * A.locs_ld;
+                if constexpr (D == 0) {
+                    for (int t = 0; t < A.dim; ++t) {
+                        const double c = lp[t];
+                        poison[q] = poison[q] | (c != c);
+                        L.xy[sub][row[q]][t] = c;
+                    }
+                } else if constexpr (D == 2) {
+                    const double2 v2 = *reinterpret_cast<const double2 *>(lp);
+                    xi[q][0] = v2.x; xi[q][1] = v2.y;
+                } else if constexpr (D == 3) {
+                    const double2 v2 = *reinterpret_cast<const double2 *>(lp);
+                    xi[q][0] = v2.x; xi[q][1] = v2.y; xi[q][2] = lp[2];
+                } else {
+#pragma unroll
+                    for (int t = 0; t < D; ++t) xi[q][t] = lp[t];
+                }
+                nugraw[q] = A.nuggets[idx[q]];
+            } else {
+                if constexpr (D != 0) {
+#pragma unroll
+                    for (int t = 0; t < D; ++t) xi[q][t] = 0.0;
+                }
+            }
+            if (valid[q] && A.z != nullptr) zi[q] = A.z[idx[q]];
+            vmask[q] = __ballot(valid[q]);
             if constexpr (D != 0) {
 #pragma unroll
-                for (int t = 0; t < D; ++t) xi[t] = 0.0;
-            }
-        }
-        if (valid && A.z != nullptr) zi = A.z[idx];
-        const unsigned long long vmask = __ballot(valid);
-        const unsigned long long onmask = __ballot(lane_on);
-        const bool all_valid = (vmask == onmask);          // wave-uniform: no padding anywhere in this task
-        const int nmiss = P - __popcll(vmask & setmask);
-        if constexpr (D != 0) {
+                for (int t = 0; t < D; ++t) poison[q] = poison[q] | (xi[q][t] != xi[q][t]);
+                if (lane_on && row[q] < P) {
 #pragma unroll
-            for (int t = 0; t < D; ++t) poison = poison | (xi[t] != xi[t]);
-            if (lane_on) {
-#pragma unroll
-                for (int t = 0; t < D; ++t) L.xy[sub][i][t] = xi[t];
+                    for (int t = 0; t < D; ++t) L.xy[sub][row[q]][t] = xi[q][t];
+                }
             }
+            if (COV == COV_DENSE && lane_on && row[q] < P) L.ix[sub][row[q]] = idx[q];
         }
-        if (COV == COV_DENSE && lane_on) L.ix[sub][i] = idx;
+        // wave-uniform: does any set of this task have padding (missing neighbours / rows beyond the data)?
+        int nvalid = 0;
+        unsigned long long rowmask_all = 0ull;
+        bool all_valid = true;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            nvalid += __popcll(vmask[q] & setmask);
+            const unsigned long long want = __ballot(lane_on && row[q] < P);
+            all_valid = all_valid && (vmask[q] == want);
+        }
+        const int nmiss = P - nvalid;
         wave_sync();
 
         // ---- covariance: every unordered pair once, circulant pairing ------------------
         constexpr int H = P / 2;
         auto cov_rounds = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
-#pragma unroll 2
-            for (int s = 1; s <= H; ++s) {
-                const unsigned tj = (unsigned)(i + s);
-                const int j = (int)(tj < tj - P ? tj : tj - P);          // (i + s) mod P via unsigned min
-                const bool act = lane_on && (((P & 1) == 1) || (s < H) || (i < H));
-                double v;
-                if constexpr (COV == COV_DENSE) {
-                    const int jx = L.ix[sub][j];
-                    v = (valid && jx >= 0) ? A.covvals[(int64_t)idx * A.nlocs + jx] : 0.0;   // src/U_NZentries.cpp:144
-                } else {
-                    double r2 = 0.0;
-                    if constexpr (D == 0) {
-                        for (int t = 0; t < A.dim; ++t) {
-                            const double df = L.xy[sub][i][t] - L.xy[sub][j][t];
-                            r2 += df * df;                       // src/dist.cpp:12-14, left to right from 0.0
-                        }
-                    } else {
 #pragma unroll
-                        for (int t = 0; t < D; ++t) {
-                            const double df = xi[t] - L.xy[sub][j][t];
-                            r2 = __builtin_fma(df, df, r2);
+            for (int q = 0; q < RPL; ++q) {
+#pragma unroll 2
+                for (int s = 1; s <= H; ++s) {
+                    const unsigned tj = (unsigned)(row[q] + s);
+                    int j = (int)(tj < tj - P ? tj : tj - P);            // (row + s) mod P via unsigned min
+                    bool act = lane_on && (((P & 1) == 1) || (s < H) || (row[q] < H));
+                    if (RPL * LPS > P) {                                    // spare slots compute nothing
+                        act = act && (row[q] < P);
+                        j = (row[q] < P) ? j : 0;
+                    }
+                    double v;
+                    if constexpr (COV == COV_DENSE) {
+                        const int jx = L.ix[sub][j];
+                        v = (valid[q] && jx >= 0) ? A.covvals[(int64_t)idx[q] * A.nlocs + jx] : 0.0;   // src/U_NZentries.cpp:144
+                    } else {
+                        double r2 = 0.0;
+                        if constexpr (D == 0) {
+                            const int rr = row[q] < P ? row[q] : 0;
+                            for (int t = 0; t < A.dim; ++t) {
+                                const double df = L.xy[sub][rr][t] - L.xy[sub][j][t];
+                                r2 += df * df;                   // src/dist.cpp:12-14, left to right from 0.0
+                            }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < D; ++t) {
+                                const double df = xi[q][t] - L.xy[sub][j][t];
+                                r2 = __builtin_fma(df, df, r2);
+                            }
+                        }
+                        v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
+                        if constexpr (MASKED) {                  // padded rows/cols -> identity
+                            bool jvalid = false;
+#pragma unroll
+                            for (int q2 = 0; q2 < RPL; ++q2) {
+                                const int jl = j - q2 * LPS;
+                                if (jl >= 0 && jl < LPS) jvalid = (vmask[q2] >> (sub * LPS + jl)) & 1ull;
+                            }
+                            v = (valid[q] && jvalid) ? v : 0.0;
                         }
                     }
-                    v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
-                    if constexpr (MASKED) {                      // padded rows/cols -> identity
-                        const bool jvalid = (vmask >> (sub * P + j)) & 1ull;
-                        v = (valid && jvalid) ? v : 0.0;
-                    }
+                    const int hi = row[q] > j ? row[q] : j, lo = row[q] > j ? j : row[q];
+                    if (act) L.tri[sub][(int)(__umul24(hi, hi + 1) >> 1) + lo] = v;
                 }
-                const int hi = i > j ? i : j, lo = i > j ? j : i;
-                if (act) L.tri[sub][(int)(__umul24(hi, hi + 1) >> 1) + lo] = v;
             }
         };
         if (all_valid) cov_rounds(std::false_type{});            // wave-uniform: the common case has no padding
         else cov_rounds(std::true_type{});
-        wave_sync();
 
-        // ---- row i of the symmetric block into registers --------------------------------
-        double a[P];
-        {
+        // ---- diagonal, data row staging, then the lane's rows into registers -----------------
+        double a[RPL][P];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
             double diag;
-            if constexpr (COV == COV_DENSE) diag = valid ? A.covvals[(int64_t)idx * A.nlocs + idx] : 1.0;
-            else diag = valid ? (sig0 + nugraw * (1.0 - (double)cnd)) : 1.0;   // src/U_NZentries.cpp:47,52
-            if (poison) diag = __builtin_nan("");
-            if (lane_on) L.tri[sub][tri_i + i] = diag;
-            wave_sync();
-            // (i,c) lives at tri_i + c for c <= i and at c(c+1)/2 + i above the diagonal: one select per column
-            const double *rowA = &L.tri[sub][tri_i];
-            const double *colB = &L.tri[sub][i];
+            if constexpr (COV == COV_DENSE) diag = valid[q] ? A.covvals[(int64_t)idx[q] * A.nlocs + idx[q]] : 1.0;
+            else diag = valid[q] ? (sig0 + nugraw[q] * (1.0 - (double)cnd[q])) : 1.0;   // src/U_NZentries.cpp:47,52
+            if (poison[q]) diag = __builtin_nan("");
+            if (lane_on && row[q] < P) {
+                L.tri[sub][(int)(__umul24(row[q], row[q] + 1) >> 1) + row[q]] = diag;
+                // data row: z_j of the neighbours conditioned on as observations (R/vecchia_likelihood.R:74)
+                if (ZROW) L.col[1][sub][row[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? zi[q] : 0.0;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            // (r,c) lives at r(r+1)/2 + c for c <= r and at c(c+1)/2 + r above the diagonal: one select per column;
+            // slot P reads the staged data row, slots beyond read zeros
+            const int r = row[q];
+            const int rc = r < P ? r : 0;
+            const double *extra = (ZROW && r == P) ? &L.col[1][sub][0] : &L.zero[0];
+            // spare slots (r >= P) always take the "c <= r" branch below: point it at the staged row instead
+            const double *rowA = (RPL * LPS > P && r >= P) ? extra : &L.tri[sub][(int)(__umul24(rc, rc + 1) >> 1)];
+            const double *colB = &L.tri[sub][rc];
 #pragma unroll
             for (int c = 0; c < P; ++c) {
-                const double *src = (i >= c) ? (rowA + c) : (colB + c * (c + 1) / 2);
-                a[c] = *src;
+                const double *src = (r >= c) ? (rowA + c) : (colB + c * (c + 1) / 2);
+                a[q][c] = *src;
             }
         }
         wave_sync();
 
         // ---- Gauss-Jordan sweep over pivots 0..P-2 ------------------------------------
-        double pown = 1.0;                             // this lane's own pivot (kept out of a[] indexing)
+        double pown[RPL], prinv[RPL];                  // each row's own pivot and its reciprocal (kept out of a[] indexing)
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) { pown[q] = 1.0; prinv[q] = 1.0; }
 #pragma unroll
         for (int j = 0; j < P - 1; ++j) {
             double *cb = L.col[j & 1][sub];
-            cb[iw] = a[j];                             // column j of the current matrix == pivot row by symmetry
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) cb[wslot[q]] = a[q][j];    // column j of the current matrix == pivot row by symmetry
             wave_sync();
             constexpr int CH = (P <= 32) ? GPV_CHUNK : 4;   // wide rows: keep the burst small, a[] already needs 2P VGPRs
             double t[2][CH];
             // burst 0 of the pivot row is in flight while the reciprocal is computed
 #pragma unroll
-            for (int q = 0; q < CH; ++q)
-                if (j + 1 + q < P) t[0][q] = cb[j + 1 + q];
+            for (int u = 0; u < CH; ++u)
+                if (j + 1 + u < P) t[0][u] = cb[j + 1 + u];
             const double pj = cb[j];                   // pivot = Schur complement d_j^2
-            pown = (i == j) ? pj : pown;
             const double rinv = rcp_pivot(pj);
-            const double aj = (i == j) ? 0.0 : a[j];   // the pivot row itself is left untouched
-            const double w = aj * rinv;
+            double w[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const bool isp = (row[q] == j);
+                pown[q] = isp ? pj : pown[q];
+                prinv[q] = isp ? rinv : prinv[q];
+                const double aj = isp ? 0.0 : a[q][j];   // the pivot row itself is left untouched
+                w[q] = aj * rinv;
+            }
 #pragma unroll
             for (int c0 = j + 1, b = 0; c0 < P; c0 += CH, b ^= 1) {
 #pragma unroll
-                for (int q = 0; q < CH; ++q)
-                    if (c0 + CH + q < P) t[b ^ 1][q] = cb[c0 + CH + q];      // next burst
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + CH + u < P) t[b ^ 1][u] = cb[c0 + CH + u];      // next burst
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < CH; ++q)
-                    if (c0 + q < P) a[c0 + q] = __builtin_fma(-w, t[b][q], a[c0 + q]);
+                for (int u = 0; u < CH; ++u)
+                    if (c0 + u < P) {
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q) a[q][c0 + u] = __builtin_fma(-w[q], t[b][u], a[q][c0 + u]);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // last pivot: v = Schur complement of the point itself
-        {
-            double *cb = L.col[(P - 1) & 1][sub];
-            cb[iw] = a[P - 1];
-            wave_sync();
+        // last column: slot P-1 = v (Schur complement of the point itself), slot P = -mu_k (data row)
+        double *cl = L.col[(P - 1) & 1][sub];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) cl[wslot[q]] = a[q][P - 1];
+        wave_sync();
+        const double vlast = cl[P - 1];
+        bool bad = false;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            pown[q] = (row[q] == P - 1) ? vlast : pown[q];
+            // LAPACK dpotrf: a pivot <= 0 or NaN -> not positive definite (src/U_NZentries.cpp:60-66)
+            bad = bad | (lane_on && row[q] < P && !(pown[q] > 0.0));
         }
-        const double vlast = L.col[(P - 1) & 1][sub][P - 1];
-        pown = (i == P - 1) ? vlast : pown;
-        // LAPACK dpotrf: a pivot <= 0 or NaN -> not positive definite (src/U_NZentries.cpp:60-66)
-        const unsigned long long badmask = __ballot(lane_on && !(pown > 0.0));
-        const bool fail = (badmask & setmask) != 0ull;
-        const double dlast = sqrt(vlast);              // R[n0-1][n0-1]
-        const double rs = 1.0 / dlast;                 // M[n0-1] = d_k
-        double x = (i == P - 1) ? rs : -(a[P - 1] / pown) * rs;
-        if (!valid || fail) x = 0.0;
+        const bool fail = (__ballot(bad) & setmask) != 0ull;
+        const double rs = rsqrt_pos(vlast);            // M[n0-1] = d_k = 1/R[n0-1][n0-1]
+        const double dlast = vlast * rs;               // R[n0-1][n0-1] = sqrt(v)
+        double x[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            x[q] = (row[q] == P - 1) ? rs : -(a[q][P - 1] * prinv[q]) * rs;
+            if (!valid[q] || fail) x[q] = 0.0;
+        }
 
         // ---- outputs -------------------------------------------------------------------
-        if ((A.flags & 1) && set_on) {
+        if (A.flags & 1) {
             const int n0 = P - nmiss;
-            const int pos = valid ? (i - nmiss) : (n0 + i);      // left-aligned, zero padded (:33,63)
-            A.Lentries[k * P + pos] = x;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                if (set_on && row[q] < P) {
+                    const int pos = valid[q] ? (row[q] - nmiss) : (n0 + row[q]);   // left-aligned, zero padded (:33,63)
+                    A.Lentries[k * P + pos] = x[q];
+                }
+            }
         }
         if (A.flags & 6) {
-            // a_k = sum over observed-conditioned neighbours of M_j z_j  (R/vecchia_likelihood.R:74)
-            double *cb = L.col[P & 1][sub];
-            cb[iw] = (valid && cnd == 0 && i != P - 1) ? x * zi : 0.0;
-            wave_sync();
-            double ak = 0.0;
+            double negmu;                              // -mu_k = -sum_j b_j z_j over observed-conditioned neighbours
+            if constexpr (ZROW) {
+                negmu = cl[P];
+            } else {
+                // no spare slot: a_k = sum_j M_j z_j through LDS (R/vecchia_likelihood.R:74), -mu_k = a_k / d_k
+                double *cb = L.col[P & 1][sub];
 #pragma unroll
-            for (int c = 0; c < P - 1; ++c) ak += cb[c];
-            if (set_on && i == P - 1) {
-                double *ac = L.acc[sub];
-                if (fail) {
-                    ac[6] += 1.0;
-                } else {
-                    const double tau = nugraw;
-                    const double tv = tau + vlast;
-                    const double rz = __builtin_fma(ak, dlast, zi);      // z_k - mu_k, mu_k = -a_k / d_k
-                    if (A.flags & 2) {
-                        ac[2] += log(tv);
-                        ac[3] += rz * rz / tv;
+                for (int q = 0; q < RPL; ++q)
+                    cb[wslot[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? x[q] * zi[q] : 0.0;
+                wave_sync();
+                double ak = 0.0;
+#pragma unroll
+                for (int c = 0; c < P - 1; ++c) ak += cb[c];
+                negmu = ak * dlast;
+            }
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                if (set_on && row[q] == P - 1) {
+                    double *ac = L.acc[sub];
+                    if (fail) {
+                        ac[6] += 1.0;
+                    } else {
+                        const double tau = nugraw[q];
+                        const double tv = tau + vlast;
+                        const double rz = zi[q] + negmu;             // z_k - mu_k
+                        if (A.flags & 2) {
+                            ac[2] += log(tv);
+                            ac[3] += rz * rz / tv;
+                        }
+                        if (A.flags & 4) {
+                            const double ak = negmu * rs;            // a_k = -mu_k d_k
+                            ac[0] += log(rs);
+                            ac[1] += ak * ak;
+                            ac[4] += zi[q] * zi[q] / tau;
+                            ac[5] += log(tau);
+                        }
                     }
-                    if (A.flags & 4) {
-                        ac[0] += log(rs);
-                        ac[1] += ak * ak;
-                        ac[4] += zi * zi / tau;
-                        ac[5] += log(tau);
-                    }
+                    ac[7] += 1.0;
                 }
-                ac[7] += 1.0;
             }
             wave_sync();
-        } else if (set_on && i == P - 1) {
-            if (fail) L.acc[sub][6] += 1.0;
-            L.acc[sub][7] += 1.0;
+        } else {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                if (set_on && row[q] == P - 1) {
+                    if (fail) L.acc[sub][6] += 1.0;
+                    L.acc[sub][7] += 1.0;
+                }
+            }
         }
     }
 
@@ -404,33 +538,40 @@ __global__ void __launch_bounds__(k_wpb(P) * 64, k_min_waves(P)) gpv_sets_kernel
 }
 
 template <int P, int D, int COV>
-hipError_t launch_sets_PDC(const SetArgs &a, int grid, hipStream_t stream)
+hipError_t launch_sets_PDC(const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
 {
-    hipLaunchKernelGGL((gpv_sets_kernel<P, D, COV>), dim3(grid), dim3(k_wpb(P) * 64), 0, stream, a);
+    constexpr int W = wpb<P, D, COV>();
+    const int64_t tasks = (a.rows + Geo<P>::SPW - 1) / Geo<P>::SPW;
+    const int64_t need = (tasks + W - 1) / W;
+    int64_t cap = (int64_t)cus * blocks_per_cu<P, D, COV>() * 4;       // a few workgroups per resident slot, grid-stride beyond
+    if (cap > kMaxGrid) cap = kMaxGrid;
+    const int grid = (int)(need < cap ? (need < 1 ? 1 : need) : cap);
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL((gpv_sets_kernel<P, D, COV>), dim3(grid), dim3(W * 64), 0, stream, a);
     return hipGetLastError();
 }
 
 template <int P, int D>
-hipError_t launch_sets_PD(const SetArgs &a, int grid, hipStream_t stream)
+hipError_t launch_sets_PD(const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
 {
     switch (a.cov) {
-        case COV_MATERN05: return launch_sets_PDC<P, D, COV_MATERN05>(a, grid, stream);
-        case COV_MATERN15: return launch_sets_PDC<P, D, COV_MATERN15>(a, grid, stream);
-        case COV_MATERN25: return launch_sets_PDC<P, D, COV_MATERN25>(a, grid, stream);
-        case COV_ESQE: return launch_sets_PDC<P, D, COV_ESQE>(a, grid, stream);
+        case COV_MATERN05: return launch_sets_PDC<P, D, COV_MATERN05>(a, cus, grid_out, stream);
+        case COV_MATERN15: return launch_sets_PDC<P, D, COV_MATERN15>(a, cus, grid_out, stream);
+        case COV_MATERN25: return launch_sets_PDC<P, D, COV_MATERN25>(a, cus, grid_out, stream);
+        case COV_ESQE: return launch_sets_PDC<P, D, COV_ESQE>(a, cus, grid_out, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
 template <int P>
-hipError_t launch_sets_P(const SetArgs &a, int grid, hipStream_t stream)
+hipError_t launch_sets_P(const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
 {
-    if (a.cov == COV_DENSE) return launch_sets_PDC<P, 1, COV_DENSE>(a, grid, stream);   // U_NZentries_mat: no coordinates
+    if (a.cov == COV_DENSE) return launch_sets_PDC<P, 1, COV_DENSE>(a, cus, grid_out, stream);   // U_NZentries_mat: no coordinates
     switch (a.dim) {
-        case 1: return launch_sets_PD<P, 1>(a, grid, stream);
-        case 2: return launch_sets_PD<P, 2>(a, grid, stream);
-        case 3: return launch_sets_PD<P, 3>(a, grid, stream);
-        default: return launch_sets_PD<P, 0>(a, grid, stream);
+        case 1: return launch_sets_PD<P, 1>(a, cus, grid_out, stream);
+        case 2: return launch_sets_PD<P, 2>(a, cus, grid_out, stream);
+        case 3: return launch_sets_PD<P, 3>(a, cus, grid_out, stream);
+        default: return launch_sets_PD<P, 0>(a, cus, grid_out, stream);
     }
 }
 
