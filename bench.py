@@ -134,7 +134,12 @@ def main():
 
     flags = G.GPV_WANT_LOGLIK_Z | (G.GPV_WANT_U if args.mode == "U" else 0)
     sums = torch.zeros(G._lib.NSUMS, dtype=torch.float64, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    # one explicit (non-null) HIP stream carries the kernel, the all-reduce and the D2H copy of every step;
+    # a NULL handle would select the plan's private stream and un-order the consumers below
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
 
     def step():
         plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())

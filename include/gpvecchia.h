@@ -133,8 +133,9 @@ int gpv_plan_set_data(gpv_plan *plan, const double *z_ord);
 /* One evaluation = what createU()+vecchia_likelihood_U() trigger per parameter
  * value (R/vecchia_likelihood.R:23-26).  nuggets: n_nuggets == 1 (constant,
  * R/createU.R:74) or == Nlocs (ordered, nuggets.all.ord of R/createU.R:77).
- * Asynchronous on `stream` (a hipStream_t, NULL = the plan's own stream); results are
- * valid after the stream is synchronised or after a blocking getter.
+ * Asynchronous on `stream` (a hipStream_t; NULL selects the plan's own non-blocking stream, NOT the HIP
+ * null stream: pass the stream your consumer of d_sums_out runs on); results are valid after that stream
+ * is synchronised or after a blocking getter.
  * If d_sums_out != NULL the GPV_NSUMS partial sums are ALSO written to that
  * device address (caller-owned, e.g. the buffer an RCCL all-reduce works on). */
 int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms,
