@@ -46,6 +46,13 @@ int cov_setup(const char *covType, const double *cp, int ncov, CovSetup &c)
         } else if (cp[2] == 2.5) {
             c.cov = COV_MATERN25;
             c.cA = std::sqrt(5.0) / cp[1];
+        } else if (cp[2] > 0.0 && cp[2] <= 60.0 && std::isfinite(cp[2])) {
+            // general smoothness: Bessel branch, src/Matern.cpp:72-84.  NOTE the reference applies no sqrt(2 nu)
+            // scaling there, so the covariance is discontinuous in nu at 0.5, 1.5, 2.5 (reproduced, not fixed).
+            c.cov = COV_MATERN_GEN;
+            c.sA = cp[0] / (std::pow(2.0, cp[2] - 1.0) * std::tgamma(cp[2]));   // normcon, :73
+            c.cA = 1.0 / cp[1];
+            c.sB = cp[2];
         } else {
             return GPV_ERR_UNSUPPORTED_NU;
         }
@@ -112,7 +119,7 @@ const char *gpv_status_string(int status)
         case GPV_ERR_NO_DEVICE: return "no usable HIP device (libgpvecchia_hip has no CPU fallback)";
         case GPV_ERR_BAD_ARG: return "bad argument";
         case GPV_ERR_COVTYPE: return "covariance is not implemented (covType must be \"matern\" or \"esqe\")";
-        case GPV_ERR_UNSUPPORTED_NU: return "Matern smoothness must be 0.5, 1.5 or 2.5 (general-nu Bessel branch not built)";
+        case GPV_ERR_UNSUPPORTED_NU: return "Matern smoothness must be finite, > 0 and <= 60";
         case GPV_ERR_UNSUPPORTED_M: return "m+1 exceeds the widest compiled conditioning-set kernel";
         case GPV_ERR_HIP: return "HIP runtime error";
         case GPV_ERR_STATE: return "call order error (no evaluation yet / no data set)";

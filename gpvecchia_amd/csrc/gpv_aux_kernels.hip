@@ -148,6 +148,8 @@ __global__ void gpv_covfun_kernel(const double *dist, int64_t n, int cov, double
         } else if (cov == COV_MATERN25) {
             const double t = d * cA;
             v = sA * exp(-t) * (1.0 + t + t * t * (1.0 / 3.0));
+        } else if (cov == COV_MATERN_GEN) {
+            v = (d == 0.0) ? sig0 : matern_general(d * cA, sA, sB);
         } else {
             v = sA * exp(-(d * cA)) + sB * exp(-(d * d * cB));
         }

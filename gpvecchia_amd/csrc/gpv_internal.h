@@ -8,7 +8,8 @@ namespace gpv {
 
 // covariance family evaluated inside the conditioning-set kernel
 //   matern branches: src/Matern.cpp:32-42 (nu .5), :43-57 (1.5), :58-71 (2.5); esqe: src/Esqe.cpp:17-39
-enum CovKind : int { COV_MATERN05 = 0, COV_MATERN15 = 1, COV_MATERN25 = 2, COV_ESQE = 3, COV_DENSE = 4 };
+//   COV_MATERN_GEN: any other smoothness, Bessel branch src/Matern.cpp:72-84 (sA = sigma^2 2^{1-nu}/Gamma(nu), cA = 1/range, sB = nu)
+enum CovKind : int { COV_MATERN05 = 0, COV_MATERN15 = 1, COV_MATERN25 = 2, COV_ESQE = 3, COV_DENSE = 4, COV_MATERN_GEN = 5 };
 
 constexpr int kNSums = 8;      // GPV_NSUMS
 constexpr int kMaxDimGeneric = 8;

@@ -34,6 +34,7 @@
 //   No MFMA (blocks are tiny), no global atomics, deterministic reductions.
 #pragma once
 #include "gpv_internal.h"
+#include "gpv_bessel.hpp"
 #include <type_traits>
 
 #ifndef GPV_MINW_SMALL
@@ -203,6 +204,8 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
     } else if constexpr (COV == COV_MATERN25) {
         const double t = dist * cA;                 // sqrt(5) * dist / range
         v = sA * exp_neg(t) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);   // src/Matern.cpp:68
+    } else if constexpr (COV == COV_MATERN_GEN) {
+        v = (r2 == 0.0) ? sig0 : matern_general(dist * cA, sA, sB);                      // src/Matern.cpp:72-84
     } else {
         v = __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));                // src/Esqe.cpp:33-35
     }
@@ -559,6 +562,7 @@ hipError_t launch_sets_PD(const SetArgs &a, int cus, int *grid_out, hipStream_t 
         case COV_MATERN15: return launch_sets_PDC<P, D, COV_MATERN15>(a, cus, grid_out, stream);
         case COV_MATERN25: return launch_sets_PDC<P, D, COV_MATERN25>(a, cus, grid_out, stream);
         case COV_ESQE: return launch_sets_PDC<P, D, COV_ESQE>(a, cus, grid_out, stream);
+        case COV_MATERN_GEN: return launch_sets_PDC<P, D, COV_MATERN_GEN>(a, cus, grid_out, stream);
         default: return hipErrorInvalidValue;
     }
 }

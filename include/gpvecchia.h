@@ -32,7 +32,7 @@ enum {
     GPV_ERR_NO_DEVICE = 1,      /* no HIP device / HIP runtime error at init        */
     GPV_ERR_BAD_ARG = 2,        /* null pointer, negative size, bad shard range      */
     GPV_ERR_COVTYPE = 3,        /* covType not "matern"/"esqe" (src/U_NZentries.cpp:27-29) */
-    GPV_ERR_UNSUPPORTED_NU = 4, /* Matern smoothness outside {0.5,1.5,2.5} (Bessel branch, src/Matern.cpp:72-84, not built yet) */
+    GPV_ERR_UNSUPPORTED_NU = 4, /* Matern smoothness not in (0, 60] or not finite                */
     GPV_ERR_UNSUPPORTED_M = 5,  /* m+1 larger than the widest compiled kernel (64)   */
     GPV_ERR_HIP = 6,            /* HIP runtime failure (alloc, copy, launch)         */
     GPV_ERR_STATE = 7,          /* call order: result requested before an eval, no data set */

@@ -79,6 +79,9 @@ def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_o
     nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)
     cp = np.ascontiguousarray(covparms, dtype=np.float64)
     code = {"matern": 0, "esqe": 1}.get(covType, 99)
+    if code == 0 and float(cp[2]) not in (0.5, 1.5, 2.5):
+        # Bessel branch (src/Matern.cpp:72-84): the C restatement has no K_nu, use the numpy one
+        return U_NZentries_numpy(n, locs, nn, cond, nug, nugo, cp)
     L = np.zeros((Nlocs, p), dtype=np.float64, order="F")
     Z = np.zeros(2 * int(n), dtype=np.float64)
     nf = _lib().oracle_U_NZentries(int(Ncores), int(n), int(Nlocs), int(d), int(p), _dptr(locs),
@@ -87,6 +90,34 @@ def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_o
     if nf < 0:
         raise ValueError(f"{covType} covariance is not implemented")      # src/U_NZentries.cpp:27-29
     return dict(Lentries=np.array(L), Zentries=Z, n_failed=int(nf))
+
+
+def U_NZentries_numpy(n, locs, nn, cond, nuggets, nuggets_obsord, covparms):
+    """src/U_NZentries.cpp:39-69,111-115 row by row in numpy (any Matern smoothness; small cases only)."""
+    from scipy.linalg import solve_triangular
+    Nlocs, p = nn.shape
+    L = np.zeros((Nlocs, p))
+    nfail = 0
+    for k in range(Nlocs):
+        inds = nn[k][nn[k] != 0] - 1                                   # :44
+        n0 = len(inds)
+        if n0 == 0:
+            continue
+        nug = nuggets[inds] * (1.0 - cond[k, p - n0:])                 # :47
+        S = MaternFun(rdist(locs[inds]), covparms) + np.diag(nug)      # :48-52
+        try:
+            Rm = np.linalg.cholesky(S).T                               # :61
+            if not np.all(np.isfinite(Rm)):
+                raise np.linalg.LinAlgError
+            e = np.zeros(n0); e[-1] = 1.0
+            L[k, :n0] = solve_triangular(Rm, e)                        # :62-63
+        except np.linalg.LinAlgError:
+            nfail += 1                                                 # :64-66
+    Z = np.zeros(2 * int(n))
+    with np.errstate(divide="ignore"):
+        Z[0::2] = -1.0 / np.sqrt(nuggets_obsord[: int(n)])
+        Z[1::2] = 1.0 / np.sqrt(nuggets_obsord[: int(n)])
+    return dict(Lentries=L, Zentries=Z, n_failed=nfail)
 
 
 def U_NZentries_mat(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covVals, covparms):

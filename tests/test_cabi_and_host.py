@@ -75,7 +75,7 @@ def test_argument_errors_before_any_device_work():
         G.U_NZentries(1, 2, locs, nn, cd, np.ones(2), np.ones(2), "gauss", [1, 1, .5])
     assert e.value.status == 3
     with pytest.raises(G.GpvError) as e:
-        G.U_NZentries(1, 2, locs, nn, cd, np.ones(2), np.ones(2), "matern", [1, 1, .7])
+        G.U_NZentries(1, 2, locs, nn, cd, np.ones(2), np.ones(2), "matern", [1, 1, -.7])
     assert e.value.status == 4
 
 

@@ -211,7 +211,7 @@ def test_failed_rows_and_errors():
         G.U_NZentries(1, 4, locs, revNN, revCond, nug, nug, "gauss", [1, .5, 1.5])
     assert e.value.status == 3
     with pytest.raises(G.GpvError) as e:
-        G.U_NZentries(1, 4, locs, revNN, revCond, nug, nug, "matern", [1, .5, 1.2])
+        G.U_NZentries(1, 4, locs, revNN, revCond, nug, nug, "matern", [1, .5, -1.2])
     assert e.value.status == 4
     bad = revNN.copy(); bad[3, 0] = 9
     with pytest.raises(G.GpvError) as e:
@@ -250,6 +250,38 @@ def test_maternfun_esqefun_reference_test():
         assert np.sum(np.abs(G.MaternFun(D, cp) - R.MaternFun(D, cp))) < 1e-10   # tests/testthat/test-MaternFun.r:37-41
     cp = [1.0, 0.3, 0.5, 0.2]
     np.testing.assert_allclose(G.EsqeFun(D, cp), R.EsqeFun(D, cp), rtol=1e-13)
+
+
+@pytest.mark.parametrize("nu", [0.1, 0.3, 0.8, 1.0, 1.2, 1.5000001, 2.0, 3.7, 6.25, 11.0])
+def test_general_nu_maternfun_vs_scipy_bessel(nu):
+    # Bessel branch of src/Matern.cpp:72-84 (boost::math::cyl_bessel_k there, scipy.special.kv in the oracle)
+    G = _need_gpu()
+    from oracle import r_side as R
+    d = np.concatenate([[0.0], np.logspace(-7, 2.2, 4000), np.linspace(1.9, 2.1, 400)])
+    for rg in (0.05, 1.0):
+        cp = [1.7, rg, nu]
+        ref = R.MaternFun(d, cp)
+        out = G.MaternFun(d, cp)
+        ok = ref > 1e-290
+        assert out[0] == 1.7
+        np.testing.assert_allclose(out[ok], ref[ok], rtol=2e-12)
+        assert np.all(np.abs(out[~ok]) < 1e-280)
+
+
+@pytest.mark.parametrize("nu", [0.8, 1.0, 2.2])
+@pytest.mark.parametrize("cond", ["z", "SGV"])
+def test_general_nu_through_the_hot_path(nu, cond):
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, m = 600, 20
+    locs, z, va = _case(n, m, 2, 44, cond)
+    cp, tau = [1.2, 0.12, nu], 0.1
+    refU = R.createU(va, cp, tau)
+    pva = _to_product_va(va)
+    U = G.createU(pva, cp, tau)
+    _assert_rows_close(U["Lentries"], refU["U_entries"]["Lentries"], va, cp, tau)
+    ll_ref = R.vecchia_likelihood_U(z, refU)
+    assert abs(G.vecchia_likelihood(z, pva, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)
 
 
 def test_m_equals_n_minus_1_exact_density():
