@@ -27,7 +27,7 @@ EXPORTS = [
     "gpv_plan_create", "gpv_plan_destroy", "gpv_plan_set_data", "gpv_plan_eval",
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
     "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms",
-    "gpv_loglik_z_from_sums", "gpv_numerator_from_sums",
+    "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
 ]
 
 
@@ -76,6 +76,7 @@ def lib():
     L.gpv_plan_last_kernel_ms.argtypes = [vp, dp]
     L.gpv_loglik_z_from_sums.argtypes = [dp, i64, dp]
     L.gpv_numerator_from_sums.argtypes = [dp, dp, dp]
+    L.gpv_whichCondOnLatent.argtypes = [ip, i64, C.c_int, i64, ip]
     _lib = L
     return L
 

@@ -542,4 +542,79 @@ void gpv_EsqeFun(const double *distmat, const int *nelem, const double *covparms
     covfun_host(distmat, nelem, cs, covmat, status);
 }
 
+// ---------------------------------------------------------------------------------------
+// host-side setup helper (parameter-independent, runs once per data set; "next" row §8f-3)
+// ---------------------------------------------------------------------------------------
+int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t firstind_pred, int *Cond)
+{
+    // R/whichCondOnLatent.R:2-26, literal semantics (is.element(NA, x) is TRUE when x holds an NA; first maximum).
+    // O(n p^2) with a stamp array instead of R's O(n p^3) nested is.element calls.
+    if (!NNarray || !Cond || n <= 0 || ncolNN < 1) return GPV_ERR_BAD_ARG;
+    const int p = ncolNN;
+    // row-major working copies (the R layout is column-major: stride n between a row's entries)
+    std::vector<int32_t> nnr((size_t)n * p);
+    std::vector<int> cdr((size_t)n * p, INT_MIN);
+    for (int c = 0; c < p; ++c)
+        for (int64_t r = 0; r < n; ++r) {
+            const int v = NNarray[r + (int64_t)c * n];
+            const int w = is_missing(v) ? 0 : v;
+            if (w < 0 || (int64_t)w > n) return GPV_ERR_INDEX;
+            nnr[(size_t)r * p + c] = w;
+        }
+    auto NN = [&](int64_t r, int c) -> int64_t { return nnr[(size_t)r * p + c]; };
+    auto CD = [&](int64_t r, int c) -> int & { return cdr[(size_t)r * p + c]; };
+    std::vector<int64_t> stamp((size_t)n + 1, -1);
+    std::vector<char> has_na((size_t)n, 0);
+    std::vector<int> latents(p);
+    CD(0, 0) = 1;                                                        // :10
+    for (int c = 0; c < p; ++c) has_na[0] |= (NN(0, c) == 0);
+    for (int64_t k = 1; k < n; ++k) {                                    // :12
+        int n_na = 0;
+        for (int c = 0; c < p; ++c) {
+            const int64_t v = NN(k, c);
+            if (v == 0) ++n_na; else stamp[v] = k;
+        }
+        has_na[k] = n_na > 0;
+        latents[0] = 0;
+        for (int ind = 1; ind < p; ++ind) {                              // :14-18
+            latents[ind] = 0;
+            const int64_t l = NN(k, ind);
+            if (l != 0 && l < firstind_pred) {
+                int cnt = 0;
+                for (int c = 0; c < p; ++c) {
+                    const int64_t u = NN(l - 1, c);
+                    if (u != 0 && CD(l - 1, c) == 1 && stamp[u] == k) ++cnt;
+                }
+                if (has_na[l - 1]) cnt += n_na;
+                latents[ind] = cnt;
+            }
+        }
+        int best = 0;
+        for (int ind = 1; ind < p; ++ind)
+            if (latents[ind] > latents[best]) best = ind;                // which(latents == max)[1]
+        const int64_t ref = NN(k, best);                                 // :19
+        // :20 — table = NNarray[ref,] * CondOnLatent[ref,]; for ref == k that row is still all NA
+        std::vector<int64_t> tab;
+        bool tab_na = true;
+        if (ref - 1 != k) {
+            tab_na = has_na[ref - 1];
+            for (int c = 0; c < p; ++c)
+                if (NN(ref - 1, c) != 0 && CD(ref - 1, c) == 1) tab.push_back(NN(ref - 1, c));
+        }
+        for (int c = 0; c < p; ++c) {
+            const int64_t v = NN(k, c);
+            if (v == 0) continue;                                        // stays NA (:23)
+            int val = 0;
+            for (int64_t t : tab) val |= (t == v);
+            if (v >= firstind_pred) val = 1;                             // :21
+            CD(k, c) = val;
+        }
+        (void)tab_na;
+        if (NN(k, 0) != 0) CD(k, 0) = 1;                                 // :22
+    }
+    for (int c = 0; c < p; ++c)
+        for (int64_t r = 0; r < n; ++r) Cond[r + (int64_t)c * n] = cdr[(size_t)r * p + c];
+    return GPV_OK;
+}
+
 }  // extern "C"

@@ -134,9 +134,11 @@ def find_ordered_nn(locs, m, workers=-1, rows=None):
     return NN
 
 
-def whichCondOnLatent(NNarray, firstind_pred=None):
+def whichCondOnLatent(NNarray, firstind_pred=None, native=True):
     """R/whichCondOnLatent.R:2-26 (SGV rule).  NNarray int (n, m+1), 1-based, 0 = NA.
     Returns int8 (n, m+1): 1 TRUE (latent), 0 FALSE (observed), -1 NA.
+    native=True runs the C++ host routine of the library (gpv_whichCondOnLatent, O(n m^2));
+    native=False the pure-Python restatement below (kept as its cross-check).
 
     R details reproduced: is.element(NA, x) is TRUE when x contains NA; the 'table' is
     NNarray[l,] * CondOnLatent[l,] (index, 0, or NA); which(...)[1] takes the first maximum."""
@@ -144,6 +146,13 @@ def whichCondOnLatent(NNarray, firstind_pred=None):
     n, p = NN.shape
     if firstind_pred is None:
         firstind_pred = n + 1
+    if native:
+        from . import _lib as L
+        nn32 = np.asfortranarray(NN.astype(np.int32))
+        out = np.empty((n, p), dtype=np.int32, order="F")
+        L.check(L.lib().gpv_whichCondOnLatent(L.iptr(nn32), n, p, int(firstind_pred), L.iptr(out)),
+                "gpv_whichCondOnLatent")
+        return np.where(out == L.NA_INTEGER, -1, out).astype(np.int8)
     Cond = np.full((n, p), -1, dtype=np.int8)
     Cond[0, 0] = 1
     na = NN == 0

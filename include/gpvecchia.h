@@ -157,6 +157,14 @@ int gpv_loglik_z_from_sums(const double *sums, int64_t n, double *loglik);
 /* numerator pieces of R/vecchia_likelihood.R:74-76: logdet.num, quadform.num */
 int gpv_numerator_from_sums(const double *sums, double *logdet_num, double *quadform_num);
 
+/* -------------------------------------------------------------------------
+ * Host-side setup helper (no GPU needed, parameter independent, once per data set).
+ * Not part of the reference's FFI: the reference runs this as interpreted R
+ * (R/whichCondOnLatent.R:2-26, O(n m^3)); exported so that SGV plans can be built at n = 1e6.
+ * NNarray: n x ncolNN column-major, 1-based, 0/NA_INTEGER = missing (NOT reversed);
+ * Cond out: n x ncolNN column-major R logical (1/0/NA_INTEGER). */
+int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t firstind_pred, int *Cond);
+
 #ifdef __cplusplus
 }
 #endif

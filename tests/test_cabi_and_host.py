@@ -124,6 +124,23 @@ def test_vecchia_specify_matches_oracle(ordering, cond):
     assert pa["size"] == pb["size"] == 600
 
 
+def test_native_whichCondOnLatent_matches_both_restatements():
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    rng = np.random.default_rng(12)
+    for n, m, d in ((60, 3, 1), (400, 9, 2), (250, 30, 3)):
+        locs = rng.random((n, d))
+        NN = S.find_ordered_nn(locs, m)
+        a = S.whichCondOnLatent(NN, native=True)
+        b = S.whichCondOnLatent(NN, native=False)
+        c = np.nan_to_num(R.whichCondOnLatent(np.where(NN == 0, np.nan, NN.astype(float))), nan=-1).astype(np.int8)
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    # prediction-style call: indices >= firstind_pred are always conditioned on as latent
+    a = S.whichCondOnLatent(NN, firstind_pred=200, native=True)
+    c = np.nan_to_num(R.whichCondOnLatent(np.where(NN == 0, np.nan, NN.astype(float)), firstind_pred=200), nan=-1)
+    assert np.array_equal(a, c.astype(np.int8))
+
+
 def test_vecchia_specify_edge_cases():
     import gpvecchia_amd as G
     locs = np.random.default_rng(0).random((20, 2))
