@@ -9,6 +9,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <numeric>
 #include <thread>
 #include <vector>
 
@@ -102,9 +104,15 @@ struct gpv_plan {
     int dim = 0, p = 0, P = 0, locs_ld = 0, grid = 1;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double *d_locs = nullptr, *d_nuggets = nullptr, *d_z = nullptr, *d_L = nullptr, *d_block = nullptr,
-           *d_sums = nullptr, *d_Z = nullptr, *d_tmp = nullptr, *d_covvals = nullptr;
-    int32_t *d_nn = nullptr;
+    // d_locs: dim <= 3: packed records [Nlocs][4] = {c0,c1,c2,data} in the plan's INTERNAL (Morton) order;
+    //         dim  > 3: coordinates [Nlocs][dim] in internal order, data in d_z
+    // d_nuggets: internal order (gathered by the kernel); d_nug_user: caller's ordered layout (Zentries)
+    double *d_locs = nullptr, *d_nuggets = nullptr, *d_nug_user = nullptr, *d_z = nullptr, *d_L = nullptr,
+           *d_block = nullptr, *d_sums = nullptr, *d_Z = nullptr, *d_tmp = nullptr, *d_covvals = nullptr,
+           *d_stage = nullptr;
+    int32_t *d_nn = nullptr, *d_newpos = nullptr, *d_rowid = nullptr;
+    double nug_scalar = 0.0;
+    bool nug_is_scalar = true;
     uint8_t *d_cond = nullptr;
     bool has_z = false, evaluated = false, have_U = false;
     hipStream_t last_stream = nullptr;
@@ -149,8 +157,8 @@ int gpv_plan_destroy(gpv_plan *pl)
     if (!pl) return GPV_OK;
     (void)hipSetDevice(pl->device);
     if (pl->stream) (void)hipStreamSynchronize(pl->stream);
-    void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
-                    pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_nn, pl->d_cond};
+    void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
+                    pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -184,7 +192,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     pl->dim = dim;
     pl->p = ncolNN;
     pl->P = P;
-    pl->locs_ld = (dim == 3) ? 4 : dim;
+    pl->locs_ld = (dim <= 3) ? 4 : dim;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
         delete pl;
@@ -193,22 +201,76 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     pl->cus = prop.multiProcessorCount;
     pl->grid = 1;
 
+    // ---- internal location order: Morton (Z-curve) sort of the coordinates.  Invisible at the ABI: only the
+    // device copies of locations / data / nuggets are permuted and the neighbour indices remapped.  The m
+    // neighbours of a point are spatially close, so their 32-byte records then share cache lines instead of
+    // costing one fabric request each (profiles/: FETCH_SIZE per launch).
+    std::vector<int32_t> newpos((size_t)Nlocs);
+    {
+        std::vector<uint64_t> key((size_t)Nlocs, 0);
+        if (locs) {
+            const int kd = dim < 3 ? dim : 3;
+            double lo[3] = {0, 0, 0}, sc[3] = {0, 0, 0};
+            for (int t = 0; t < kd; ++t) {
+                double mn = INFINITY, mx = -INFINITY;
+                for (int64_t i = 0; i < Nlocs; ++i) {
+                    const double v = locs[i + (int64_t)t * Nlocs];
+                    if (v == v) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
+                }
+                lo[t] = mn;
+                sc[t] = (mx > mn) ? 2097151.0 / (mx - mn) : 0.0;       // 21 bits per dimension
+            }
+            parallel_for(Nlocs, [&, kd](int64_t b, int64_t e) {
+                for (int64_t i = b; i < e; ++i) {
+                    uint64_t k = 0;
+                    uint32_t q[3] = {0, 0, 0};
+                    for (int t = 0; t < kd; ++t) {
+                        const double v = (locs[i + (int64_t)t * Nlocs] - lo[t]) * sc[t];
+                        q[t] = (v == v && v > 0) ? (uint32_t)(v < 2097151.0 ? v : 2097151.0) : 0u;
+                    }
+                    for (int bit = 20; bit >= 0; --bit)
+                        for (int t = 0; t < kd; ++t) k = (k << 1) | ((q[t] >> bit) & 1u);
+                    key[(size_t)i] = k;
+                }
+            });
+        }
+        std::vector<int32_t> order((size_t)Nlocs);
+        std::iota(order.begin(), order.end(), 0);
+        if (locs) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+        for (int64_t r = 0; r < Nlocs; ++r) newpos[(size_t)order[(size_t)r]] = (int32_t)r;
+    }
+    const int32_t *np_ = newpos.data();
+
     // ---- host re-layout: column-major 1-based R matrices -> row-major, 0-based, right-aligned rows
     const int64_t rows = pl->rows;
     std::vector<int32_t> nn((size_t)(rows > 0 ? rows : 1) * P, -1);
     std::vector<uint8_t> cd((size_t)(rows > 0 ? rows : 1) * P, 1);
     std::vector<int> err_flag(1, GPV_OK);
     int *errp = err_flag.data();
-    parallel_for(rows, [=, &nn, &cd](int64_t b, int64_t e) {
+    // stored set s <- conditioning set (row) rowsrc[s]: rows sorted by the Morton position of the point they belong
+    // to (the last entry of the row, R/U_sparsity.R:32), so that sets processed together share neighbours in L2
+    std::vector<int32_t> rowsrc((size_t)(rows > 0 ? rows : 1), 0);
+    {
+        std::iota(rowsrc.begin(), rowsrc.begin() + rows, 0);
+        std::vector<int32_t> selfpos((size_t)(rows > 0 ? rows : 1), 0);
+        for (int64_t r = 0; r < rows; ++r) {
+            const int v = revNN[(row_begin + r) + (int64_t)(ncolNN - 1) * Nlocs];
+            selfpos[(size_t)r] = (!is_missing(v) && v >= 1 && (int64_t)v <= Nlocs) ? np_[v - 1] : 0;
+        }
+        std::stable_sort(rowsrc.begin(), rowsrc.begin() + rows,
+                         [&](int32_t a, int32_t b) { return selfpos[a] < selfpos[b]; });
+    }
+    const int32_t *rs_ = rowsrc.data();
+    parallel_for(rows, [=, &nn, &cd](int64_t b, int64_t e) {   // (np_, rs_ captured by value)
         std::vector<int32_t> tmp(ncolNN);
         for (int64_t r = b; r < e; ++r) {
-            const int64_t k = row_begin + r;
+            const int64_t k = row_begin + rs_[r];
             int n0 = 0;
             for (int j = 0; j < ncolNN; ++j) {            // src/U_NZentries.cpp:44: non-zero entries, compacted, -1
                 const int v = revNN[k + (int64_t)j * Nlocs];
                 if (is_missing(v)) continue;
                 if (v < 1 || (int64_t)v > Nlocs) { *errp = GPV_ERR_INDEX; continue; }
-                tmp[n0++] = v - 1;
+                tmp[n0++] = np_[v - 1];
             }
             int32_t *nr = &nn[(size_t)r * P];
             uint8_t *cr = &cd[(size_t)r * P];
@@ -234,7 +296,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
         const int ld = pl->locs_ld;
         parallel_for(Nlocs, [=, &lr](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i)
-                for (int t = 0; t < dim; ++t) lr[(size_t)i * ld + t] = locs[i + (int64_t)t * Nlocs];
+                for (int t = 0; t < dim; ++t) lr[(size_t)np_[i] * ld + t] = locs[i + (int64_t)t * Nlocs];
         });
     }
 
@@ -254,6 +316,13 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     if (hipMemcpy(pl->d_nn, nn.data(), nnb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMemcpy(pl->d_cond, cd.data(), cdb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMemcpy(pl->d_locs, lr.data(), lrb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_rowid, sizeof(int32_t) * rowsrc.size()) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMemcpy(pl->d_rowid, rowsrc.data(), sizeof(int32_t) * rowsrc.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_newpos, sizeof(int32_t) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMalloc((void **)&pl->d_stage, sizeof(double) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (hipMemcpy(pl->d_newpos, newpos.data(), sizeof(int32_t) * (size_t)Nlocs, hipMemcpyHostToDevice) != hipSuccess)
+        return fail(GPV_ERR_HIP);
     *out = pl;
     return GPV_OK;
 }
@@ -262,8 +331,14 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
 {
     if (!pl || !z_ord) return GPV_ERR_BAD_ARG;
     GPV_HIP(hipSetDevice(pl->device));
-    if (!pl->d_z) GPV_HIP(hipMalloc((void **)&pl->d_z, sizeof(double) * (size_t)pl->Nlocs));
-    GPV_HIP(hipMemcpy(pl->d_z, z_ord, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyHostToDevice));
+    GPV_HIP(hipMemcpyAsync(pl->d_stage, z_ord, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyHostToDevice, pl->stream));
+    if (pl->dim <= 3) {
+        GPV_HIP(launch_scatter(pl->d_stage, pl->d_newpos, pl->Nlocs, pl->d_locs, 4, 3, pl->stream));   // rec[.][3] = datum
+    } else {
+        if (!pl->d_z) GPV_HIP(hipMalloc((void **)&pl->d_z, sizeof(double) * (size_t)pl->Nlocs));
+        GPV_HIP(launch_scatter(pl->d_stage, pl->d_newpos, pl->Nlocs, pl->d_z, 1, 0, pl->stream));
+    }
+    GPV_HIP(hipStreamSynchronize(pl->stream));
     pl->has_z = true;
     return GPV_OK;
 }
@@ -280,19 +355,27 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     if (cs.cov != COV_DENSE) {
         if (!nuggets) return GPV_ERR_BAD_ARG;
         if (n_nuggets == 1) {
-            GPV_HIP(launch_fill(pl->d_nuggets, nuggets[0], pl->Nlocs, st));     // R/createU.R:74
+            pl->nug_is_scalar = true;                                         // R/createU.R:74
+            pl->nug_scalar = nuggets[0];
         } else if (n_nuggets == pl->Nlocs) {
-            GPV_HIP(hipMemcpyAsync(pl->d_nuggets, nuggets, sizeof(double) * (size_t)pl->Nlocs,
+            pl->nug_is_scalar = false;
+            if (!pl->d_nug_user)
+                GPV_HIP(hipMalloc((void **)&pl->d_nug_user, sizeof(double) * (size_t)pl->Nlocs));
+            GPV_HIP(hipMemcpyAsync(pl->d_nug_user, nuggets, sizeof(double) * (size_t)pl->Nlocs,
                                    hipMemcpyHostToDevice, st));
+            GPV_HIP(launch_scatter(pl->d_nug_user, pl->d_newpos, pl->Nlocs, pl->d_nuggets, 1, 0, st));
         } else {
             return GPV_ERR_BAD_ARG;
         }
     }
     SetArgs a;
+    a.rec = pl->d_locs;
     a.locs = pl->d_locs;
     a.nn = pl->d_nn;
     a.cond = pl->d_cond;
-    a.nuggets = pl->d_nuggets;
+    a.rowid = pl->d_rowid;
+    a.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nuggets;
+    a.nug_scalar = pl->nug_scalar;
     a.z = (flags & (GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR)) ? pl->d_z : nullptr;
     a.covvals = pl->d_covvals;
     a.Lentries = (flags & GPV_WANT_U) ? pl->d_L : nullptr;
@@ -355,7 +438,12 @@ int gpv_plan_get_Zentries(gpv_plan *pl, double *Z)
     if (pl->rows == 0) return GPV_OK;
     GPV_HIP(hipSetDevice(pl->device));
     if (!pl->d_Z) GPV_HIP(hipMalloc((void **)&pl->d_Z, sizeof(double) * 2 * (size_t)pl->rows));
-    GPV_HIP(launch_zentries(pl->d_nuggets + pl->row_begin, pl->rows, pl->d_Z, pl->last_stream));
+    if (pl->nug_is_scalar) {
+        GPV_HIP(launch_fill(pl->d_stage, pl->nug_scalar, pl->rows, pl->last_stream));
+        GPV_HIP(launch_zentries(pl->d_stage, pl->rows, pl->d_Z, pl->last_stream));
+    } else {
+        GPV_HIP(launch_zentries(pl->d_nug_user + pl->row_begin, pl->rows, pl->d_Z, pl->last_stream));
+    }
     GPV_HIP(hipMemcpyAsync(Z, pl->d_Z, sizeof(double) * 2 * (size_t)pl->rows, hipMemcpyDeviceToHost, pl->last_stream));
     GPV_HIP(hipStreamSynchronize(pl->last_stream));
     return GPV_OK;

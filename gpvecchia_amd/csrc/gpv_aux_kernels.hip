@@ -81,6 +81,19 @@ hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s)
     return hipGetLastError();
 }
 
+__global__ void gpv_scatter_kernel(const double *src, const int32_t *pos, int64_t n, double *dst, int stride, int offset)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[(int64_t)pos[i] * stride + offset] = src[i];
+}
+hipError_t launch_scatter(const double *src, const int32_t *pos, int64_t n, double *dst, int stride, int offset, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gpv_scatter_kernel, dim3(grid), dim3(256), 0, s, src, pos, n, dst, stride, offset);
+    return hipGetLastError();
+}
+
 // src/U_NZentries.cpp:111-115: Z[2i] = -1/sqrt(tau_i), Z[2i+1] = +1/sqrt(tau_i)
 __global__ void gpv_zentries_kernel(const double *nug, int64_t n, double *Z)
 {

@@ -17,11 +17,13 @@ constexpr int kMaxGrid = 16384;   // upper bound of the conditioning-set grid (b
 
 // arguments of one conditioning-set launch (passed by value)
 struct SetArgs {
-    const double *locs;      // [Nlocs][locs_ld] row-major coordinates (device)
+    const double *rec;       // dim <= 3: [Nlocs][4] packed records {c0, c1, c2, data}: ONE 32-byte gather per neighbour
+    const double *locs;      // dim  > 3: [Nlocs][locs_ld] row-major coordinates (device)
     const int32_t *nn;       // [rows][P] 0-based neighbour index, -1 = missing; valid entries are the LAST n0
     const uint8_t *cond;     // [rows][P] 1 = condition on latent y, 0 = on observed z
-    const double *nuggets;   // [Nlocs]
-    const double *z;         // [Nlocs] ordered data or nullptr
+    const int32_t *rowid;    // [rows] output row of each stored set (sets are stored in Morton order of their own location)
+    const double *nuggets;   // [Nlocs] per-location nuggets, or nullptr when the nugget is the constant nug_scalar
+    const double *z;         // dim > 3 only: [Nlocs] ordered data or nullptr (dim <= 3: inside rec)
     const double *covvals;   // COV_DENSE: [Nlocs][Nlocs] symmetric covariance (U_NZentries_mat) or nullptr
     double *Lentries;        // [rows][P] row-major, left-aligned, or nullptr
     double *block_sums;      // [grid][kNSums]
@@ -35,6 +37,7 @@ struct SetArgs {
     //   matern: sig0 = sigma^2 (value at distance 0), sA = sigma^2, cA = sqrt(2nu)/range (nu=.5: 1/range)
     //   esqe:   sig0 = s1+s2, sA = s1, cA = 1/r1, sB = s2, cB = 1/r2^2
     double sig0, sA, cA, sB, cB;
+    double nug_scalar;       // constant nugget (R/createU.R:74) when nuggets == nullptr
 };
 
 // launch the conditioning-set kernel compiled for row length P (one of gpv_plist.h); the grid is chosen from
@@ -47,6 +50,8 @@ int max_P();
 // small helper kernels (gpv_aux_kernels.hip)
 hipError_t launch_reduce_sums(const double *block_sums, int nblocks, double *sums, double *sums_copy, hipStream_t s);
 hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);
+// dst[pos[i] * stride + offset] = src[i]
+hipError_t launch_scatter(const double *src, const int32_t *pos, int64_t n, double *dst, int stride, int offset, hipStream_t s);
 hipError_t launch_zentries(const double *nuggets_obsord, int64_t n, double *Z, hipStream_t s);
 hipError_t launch_rows_to_colmajor(const double *src, int ld, int64_t rows, int cols, double *dst, hipStream_t s);
 hipError_t launch_covfun(const double *dist, int64_t n, int cov, double sig0, double sA, double cA, double sB,

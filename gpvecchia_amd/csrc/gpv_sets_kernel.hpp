@@ -266,31 +266,31 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             nugraw[q] = 0.0;
             zi[q] = 0.0;
             if (valid[q] && COV != COV_DENSE) {
-                const double *lp = A.locs + (int64_t)idx[q] * A.locs_ld;
                 if constexpr (D == 0) {
+                    const double *lp = A.locs + (int64_t)idx[q] * A.locs_ld;
                     for (int t = 0; t < A.dim; ++t) {
                         const double c = lp[t];
                         poison[q] = poison[q] | (c != c);
                         L.xy[sub][row[q]][t] = c;
                     }
-                } else if constexpr (D == 2) {
-                    const double2 v2 = *reinterpret_cast<const double2 *>(lp);
-                    xi[q][0] = v2.x; xi[q][1] = v2.y;
-                } else if constexpr (D == 3) {
-                    const double2 v2 = *reinterpret_cast<const double2 *>(lp);
-                    xi[q][0] = v2.x; xi[q][1] = v2.y; xi[q][2] = lp[2];
+                    if (A.z != nullptr) zi[q] = A.z[idx[q]];
                 } else {
-#pragma unroll
-                    for (int t = 0; t < D; ++t) xi[q][t] = lp[t];
+                    // one 32-byte record per neighbour: coordinates and the datum travel together
+                    const double2 *rp = reinterpret_cast<const double2 *>(A.rec + (int64_t)idx[q] * 4);
+                    const double2 r0 = rp[0], r1 = rp[1];
+                    xi[q][0] = r0.x;
+                    if constexpr (D >= 2) xi[q][1] = r0.y;
+                    if constexpr (D >= 3) xi[q][2] = r1.x;
+                    zi[q] = r1.y;
                 }
-                nugraw[q] = A.nuggets[idx[q]];
+                nugraw[q] = (A.nuggets != nullptr) ? A.nuggets[idx[q]] : A.nug_scalar;
             } else {
                 if constexpr (D != 0) {
 #pragma unroll
                     for (int t = 0; t < D; ++t) xi[q][t] = 0.0;
                 }
+                if (valid[q] && COV == COV_DENSE && A.z != nullptr) zi[q] = A.z[idx[q]];
             }
-            if (valid[q] && A.z != nullptr) zi[q] = A.z[idx[q]];
             vmask[q] = __ballot(valid[q]);
             if constexpr (D != 0) {
 #pragma unroll
@@ -469,11 +469,12 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         // ---- outputs -------------------------------------------------------------------
         if (A.flags & 1) {
             const int n0 = P - nmiss;
+            const int64_t kout = set_on ? (int64_t)A.rowid[k] : 0;     // row of Lentries this stored set belongs to
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 if (set_on && row[q] < P) {
                     const int pos = valid[q] ? (row[q] - nmiss) : (n0 + row[q]);   // left-aligned, zero padded (:33,63)
-                    A.Lentries[k * P + pos] = x[q];
+                    A.Lentries[kout * P + pos] = x[q];
                 }
             }
         }
