@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib as L
 from . import specify as S
-from ._lib import GPV_WANT_LOGLIK_Z, GPV_WANT_NUMERATOR, GPV_WANT_U, NSUMS, GpvError
+from ._lib import GPV_WANT_DENOM, GPV_WANT_LOGLIK_Z, GPV_WANT_NUMERATOR, GPV_WANT_U, NSUMS, GpvError
 
 
 # ---------------------------------------------------------------------------
@@ -44,6 +44,16 @@ class Plan:
                                      L.iptr(nn), L.iptr(cd), self.row_begin, self.row_end)
         L.check(st, "gpv_plan_create")
         self.device = device
+        self._nn, self._cd = nn, cd          # kept for build_posterior (the R-layout arrays of this plan)
+        self.has_posterior = False
+
+    def build_posterior(self):
+        """Structure of the U2V pass (R/vecchia_prediction.R:62-83) for GPV_WANT_DENOM evaluations."""
+        L.check(L.lib().gpv_plan_build_posterior(self._h, L.iptr(self._nn), L.iptr(self._cd)), "gpv_plan_build_posterior")
+        self.has_posterior = True
+        nl = C.c_int()
+        L.check(L.lib().gpv_plan_posterior_levels(self._h, C.byref(nl)), "gpv_plan_posterior_levels")
+        return int(nl.value)
 
     def __del__(self):
         try:
@@ -104,6 +114,14 @@ def loglik_z_from_sums(sums, n):
     out = C.c_double()
     s = np.ascontiguousarray(sums, dtype=np.float64)
     L.check(L.lib().gpv_loglik_z_from_sums(L.dptr(s), int(n), C.byref(out)), "gpv_loglik_z_from_sums")
+    return float(out.value)
+
+
+def loglik_from_sums(sums, n):
+    """R/vecchia_likelihood.R:95-96 from sums evaluated with GPV_WANT_DENOM."""
+    out = C.c_double()
+    s = np.ascontiguousarray(sums, dtype=np.float64)
+    L.check(L.lib().gpv_loglik_from_sums(L.dptr(s), int(n), C.byref(out)), "gpv_loglik_from_sums")
     return float(out.value)
 
 
@@ -380,5 +398,16 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         plan.eval(covmodel, covparms, nug_all_ord if nugf.size > 1 and not np.all(nugf == nugf[0]) else nugf[:1],
                   GPV_WANT_LOGLIK_Z)
         return loglik_z_from_sums(plan.sums(), n)
+    if va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0) and not va.get("ic0", False):
+        # default mode: U, the numerator AND the posterior pass (U2V) on the GPU; SGV has no fill, so the
+        # fixed-pattern factorisation equals the reference's Matrix::chol (R/vecchia_prediction.R:80)
+        plan = _plan_for(va, device)
+        if not plan.has_posterior:
+            plan.build_posterior()
+        plan.set_data(z[va["ord_z"] - 1])
+        nug_all_ord, _, nugf = _ordered_nuggets(va, nug, n)
+        plan.eval(covmodel, covparms, nug_all_ord if nugf.size > 1 and not np.all(nugf == nugf[0]) else nugf[:1],
+                  GPV_WANT_DENOM)
+        return loglik_from_sums(plan.sums(), n)
     U_obj = createU(va, covparms, nug, covmodel, device=device)
     return vecchia_likelihood_U(z, U_obj)

@@ -57,7 +57,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
         LIB = os.path.join(HERE, f"libgpvecchia_hip{tag}.so")
     extra_flags = list(extra_flags or [])
     os.makedirs(BUILD, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in ("gpv_internal.h", "gpv_sets_kernel.hpp", "gpv_plist.h")]
+    hdrs = [os.path.join(CSRC, f) for f in ("gpv_internal.h", "gpv_sets_kernel.hpp", "gpv_plist.h", "gpv_bessel.hpp")]
     hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gpvecchia.h"))
     work = []
     for P in plist():
@@ -65,6 +65,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
                      [f"-DGPV_INST_P={P}"] + extra_flags, hdrs, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), [], hdrs, force))
     work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), [], hdrs, force))
+    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), [], hdrs, force))
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(jobs) as ex:
         res = list(ex.map(_compile, work))

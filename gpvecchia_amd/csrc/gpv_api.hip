@@ -111,6 +111,13 @@ struct gpv_plan {
            *d_block = nullptr, *d_sums = nullptr, *d_Z = nullptr, *d_tmp = nullptr, *d_covvals = nullptr,
            *d_stage = nullptr;
     int32_t *d_nn = nullptr, *d_newpos = nullptr, *d_rowid = nullptr;
+    // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
+    bool have_post = false;
+    int32_t *d_colptr = nullptr, *d_crow = nullptr, *d_rowptr = nullptr, *d_rcol = nullptr, *d_order = nullptr;
+    uint8_t *d_cslot = nullptr, *d_rslot = nullptr;
+    double *d_R = nullptr, *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
+           *d_post2 = nullptr, *d_zuser = nullptr;
+    std::vector<int32_t> levptr;
     double nug_scalar = 0.0;
     bool nug_is_scalar = true;
     uint8_t *d_cond = nullptr;
@@ -158,7 +165,9 @@ int gpv_plan_destroy(gpv_plan *pl)
     (void)hipSetDevice(pl->device);
     if (pl->stream) (void)hipStreamSynchronize(pl->stream);
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
-                    pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond};
+                    pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
+                    pl->d_colptr, pl->d_crow, pl->d_rowptr, pl->d_rcol, pl->d_order, pl->d_cslot, pl->d_rslot,
+                    pl->d_R, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -338,6 +347,8 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
         if (!pl->d_z) GPV_HIP(hipMalloc((void **)&pl->d_z, sizeof(double) * (size_t)pl->Nlocs));
         GPV_HIP(launch_scatter(pl->d_stage, pl->d_newpos, pl->Nlocs, pl->d_z, 1, 0, pl->stream));
     }
+    if (!pl->d_zuser) GPV_HIP(hipMalloc((void **)&pl->d_zuser, sizeof(double) * (size_t)pl->Nlocs));
+    GPV_HIP(hipMemcpyAsync(pl->d_zuser, pl->d_stage, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyDeviceToDevice, pl->stream));
     GPV_HIP(hipStreamSynchronize(pl->stream));
     pl->has_z = true;
     return GPV_OK;
@@ -346,6 +357,10 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
 static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nuggets, int64_t n_nuggets, int flags,
                           void *stream_v, double *d_sums_out)
 {
+    if (flags & GPV_WANT_DENOM) {
+        if (!pl->have_post) return GPV_ERR_STATE;
+        flags |= GPV_WANT_U | GPV_WANT_NUMERATOR;
+    }
     if ((flags & (GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR)) && !pl->has_z) return GPV_ERR_STATE;
     GPV_HIP(hipSetDevice(pl->device));
     hipStream_t st = stream_v ? (hipStream_t)stream_v : pl->stream;
@@ -379,6 +394,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.z = (flags & (GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR)) ? pl->d_z : nullptr;
     a.covvals = pl->d_covvals;
     a.Lentries = (flags & GPV_WANT_U) ? pl->d_L : nullptr;
+    a.aout = (flags & GPV_WANT_DENOM) ? pl->d_avec : nullptr;
     a.block_sums = pl->d_block;
     a.rows = pl->rows;
     a.nlocs = pl->Nlocs;
@@ -391,6 +407,20 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
+    if (flags & GPV_WANT_DENOM) {
+        PostArgs pa;
+        pa.colptr = pl->d_colptr; pa.crow = pl->d_crow; pa.cslot = pl->d_cslot;
+        pa.rowptr = pl->d_rowptr; pa.rcol = pl->d_rcol; pa.rslot = pl->d_rslot;
+        pa.order = pl->d_order;
+        pa.L = pl->d_L; pa.R = pl->d_R; pa.avec = pl->d_avec; pa.z = pl->d_zuser;
+        pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
+        pa.nug_scalar = pl->nug_scalar;
+        pa.tvec = pl->d_tvec; pa.logr = pl->d_logr; pa.ld = pl->P;
+        for (size_t lv = 0; lv + 1 < pl->levptr.size(); ++lv)
+            GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], st));
+        GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_post2, st));
+        GPV_HIP(launch_patch_denominator(pl->d_post2, pl->d_sums, d_sums_out, st));
+    }
     pl->evaluated = true;
     pl->have_U = (flags & GPV_WANT_U) != 0;
     pl->last_stream = st;
@@ -405,6 +435,108 @@ int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int
     const int st = cov_setup(covType, covparms, ncovparms, cs);
     if (st != GPV_OK) return st;
     return plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
+}
+
+int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
+{
+    // symbolic structure of the latent block B of U (R/U_sparsity.R:36-56 restricted to latent rows) as column
+    // lists, row lists and a level schedule; parameter independent, built once.
+    if (!pl || !revNN || !revCond) return GPV_ERR_BAD_ARG;
+    if (pl->row_begin != 0 || pl->row_end != pl->Nlocs) return GPV_ERR_BAD_ARG;   // not shardable
+    if (pl->Nlocs >= (int64_t)1 << 31) return GPV_ERR_BAD_ARG;
+    const int64_t n = pl->Nlocs;
+    const int p = pl->p;
+    std::vector<int32_t> colptr((size_t)n + 1, 0), rowcnt((size_t)n + 1, 0);
+    std::vector<int32_t> crow;
+    std::vector<uint8_t> cslot;
+    crow.reserve((size_t)n * 12);
+    cslot.reserve((size_t)n * 12);
+    std::vector<int32_t> tmp(p);
+    for (int64_t k = 0; k < n; ++k) {
+        int n0 = 0;
+        for (int j = 0; j < p; ++j) {
+            const int v = revNN[k + (int64_t)j * n];
+            if (is_missing(v)) continue;
+            if (v < 1 || (int64_t)v > n) return GPV_ERR_INDEX;
+            tmp[n0++] = v - 1;
+        }
+        if (n0 == 0 || tmp[n0 - 1] != (int32_t)k) return GPV_ERR_BAD_ARG;        // last entry must be the point itself
+        for (int t = 0; t < n0; ++t) {
+            const int c = revCond[k + (int64_t)(p - n0 + t) * n];
+            const bool latent = (c != 0 && c != INT_MIN);
+            if (t == n0 - 1 && !latent) return GPV_ERR_BAD_ARG;
+            if (latent) {
+                if (tmp[t] > (int32_t)k) return GPV_ERR_BAD_ARG;                  // neighbours precede the point
+                crow.push_back(tmp[t]);
+                cslot.push_back((uint8_t)t);
+                rowcnt[(size_t)tmp[t] + 1]++;
+            }
+        }
+        colptr[(size_t)k + 1] = (int32_t)crow.size();
+    }
+    const size_t nnz = crow.size();
+    std::vector<int32_t> rowptr((size_t)n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) rowptr[(size_t)i + 1] = rowptr[(size_t)i] + rowcnt[(size_t)i + 1];
+    std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1), rcol(nnz);
+    std::vector<uint8_t> rslot(nnz);
+    for (int64_t k = 0; k < n; ++k)                        // ascending k => every row list ascends
+        for (int32_t e = colptr[(size_t)k]; e < colptr[(size_t)k + 1]; ++e) {
+            const int32_t i = crow[(size_t)e];
+            rcol[(size_t)fill[(size_t)i]] = (int32_t)k;
+            rslot[(size_t)fill[(size_t)i]] = cslot[(size_t)e];
+            fill[(size_t)i]++;
+        }
+    // level of column k = 1 + max level of the columns c > k that contain row k
+    std::vector<int32_t> lev((size_t)n, 0);
+    int32_t maxlev = 0;
+    for (int64_t k = n - 1; k >= 0; --k) {
+        int32_t l = 0;
+        for (int32_t q = rowptr[(size_t)k]; q < rowptr[(size_t)k + 1]; ++q) {
+            const int32_t c = rcol[(size_t)q];
+            if (c > (int32_t)k && lev[(size_t)c] + 1 > l) l = lev[(size_t)c] + 1;
+        }
+        lev[(size_t)k] = l;
+        if (l > maxlev) maxlev = l;
+    }
+    pl->levptr.assign((size_t)maxlev + 2, 0);
+    for (int64_t k = 0; k < n; ++k) pl->levptr[(size_t)lev[(size_t)k] + 1]++;
+    for (int32_t l = 0; l <= maxlev; ++l) pl->levptr[(size_t)l + 1] += pl->levptr[(size_t)l];
+    std::vector<int32_t> pos(pl->levptr.begin(), pl->levptr.end() - 1), order((size_t)n);
+    for (int64_t k = n - 1; k >= 0; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
+
+    GPV_HIP(hipSetDevice(pl->device));
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return GPV_ERR_HIP;
+        if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return GPV_ERR_HIP;
+        return GPV_OK;
+    };
+    int rc = GPV_OK;
+    if ((rc = up((void **)&pl->d_colptr, colptr.data(), colptr.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_crow, crow.data(), nnz * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_cslot, cslot.data(), nnz)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_rowptr, rowptr.data(), rowptr.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_rcol, rcol.data(), nnz * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_rslot, rslot.data(), nnz)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_order, order.data(), order.size() * 4)) != GPV_OK) return rc;
+    const size_t nd = sizeof(double) * (size_t)n;
+    if (!pl->d_R) GPV_HIP(hipMalloc((void **)&pl->d_R, nd * pl->P));
+    if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
+    if (!pl->d_tvec) GPV_HIP(hipMalloc((void **)&pl->d_tvec, nd));
+    if (!pl->d_logr) GPV_HIP(hipMalloc((void **)&pl->d_logr, nd));
+    if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 512));
+    if (!pl->d_post2) GPV_HIP(hipMalloc((void **)&pl->d_post2, sizeof(double) * 2));
+    if (!pl->d_L) GPV_HIP(hipMalloc((void **)&pl->d_L, nd * pl->P));
+    pl->have_post = true;
+    return GPV_OK;
+}
+
+int gpv_plan_posterior_levels(gpv_plan *pl, int *n_levels)
+{
+    if (!pl || !n_levels) return GPV_ERR_BAD_ARG;
+    if (!pl->have_post) return GPV_ERR_STATE;
+    *n_levels = (int)pl->levptr.size() - 1;
+    return GPV_OK;
 }
 
 int gpv_plan_get_sums(gpv_plan *pl, double *sums)
@@ -487,6 +619,17 @@ int gpv_loglik_z_from_sums(const double *s, int64_t n, double *loglik)
         return GPV_OK;
     }
     *loglik = -0.5 * (s[2] + s[3] + (double)n * std::log(2.0 * M_PI));
+    return GPV_OK;
+}
+
+int gpv_loglik_from_sums(const double *s, int64_t n, double *loglik)
+{
+    // R/vecchia_likelihood.R:95-96 with logdet.num = -2 s0 + s5, quadform.num = s1 + s4 (numerator sums) and, from the
+    // posterior pass (GPV_WANT_DENOM), logdet.denom = -s2 (s2 = log det W), quadform.denom = s3
+    if (!s || !loglik) return GPV_ERR_BAD_ARG;
+    if (s[6] > 0.0) { *loglik = NAN; return GPV_OK; }
+    const double neg2 = (-2.0 * s[0] + s[5]) + s[2] + (s[1] + s[4]) - s[3] + (double)n * std::log(2.0 * M_PI);
+    *loglik = -0.5 * neg2;
     return GPV_OK;
 }
 

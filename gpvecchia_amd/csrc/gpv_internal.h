@@ -26,6 +26,7 @@ struct SetArgs {
     const double *z;         // dim > 3 only: [Nlocs] ordered data or nullptr (dim <= 3: inside rec)
     const double *covvals;   // COV_DENSE: [Nlocs][Nlocs] symmetric covariance (U_NZentries_mat) or nullptr
     double *Lentries;        // [rows][P] row-major, left-aligned, or nullptr
+    double *aout;            // [rows] a_k = sum_j M_j z_j over observed-conditioned neighbours (R/vecchia_likelihood.R:74) or nullptr
     double *block_sums;      // [grid][kNSums]
     int64_t rows;            // conditioning sets in this launch
     int64_t nlocs;
@@ -56,5 +57,31 @@ hipError_t launch_zentries(const double *nuggets_obsord, int64_t n, double *Z, h
 hipError_t launch_rows_to_colmajor(const double *src, int ld, int64_t rows, int cols, double *dst, hipStream_t s);
 hipError_t launch_covfun(const double *dist, int64_t n, int cov, double sig0, double sA, double cA, double sB,
                          double cB, double *out, hipStream_t s);
+
+// ---- posterior ("U2V") pass for cond.yz='SGV': sparse UL factor of W = U_y U_y^T on the pattern of the latent
+// block of U (zero fill for SGV), fused with the triangular solve; R/vecchia_prediction.R:62-83,
+// R/vecchia_likelihood.R:85-90.  All index arrays are in ORDERING index space.
+struct PostArgs {
+    const int32_t *colptr;   // [n+1] latent entries of column k: rows crow[], slots cslot[] (slot = position in Lentries row k)
+    const int32_t *crow;
+    const uint8_t *cslot;
+    const int32_t *rowptr;   // [n+1] row lists: columns rcol[] (ascending, first = the row itself), slots rslot[]
+    const int32_t *rcol;
+    const uint8_t *rslot;
+    const int32_t *order;    // columns sorted by level
+    const double *L;         // [n][ld] Lentries (values of the latent block B)
+    double *R;               // [n][ld] factor values, same layout
+    const double *avec;      // [n] a_k
+    const double *z;         // [n] ordered data
+    const double *nuggets;   // [n] ordered nuggets or nullptr
+    double nug_scalar;
+    double *tvec;            // [n] solution of R t = z2
+    double *logr;            // [n] log R_kk
+    int ld;
+};
+hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s);
+// out[0] = sum x[i], out[1] = sum y[i]^2, fixed order (n <= 2^31)
+hipError_t launch_patch_denominator(const double *post2, double *sums, double *sums_copy, hipStream_t s);
+hipError_t launch_sum_pair(const double *x, const double *y, int64_t n, double *partials, double *out, hipStream_t s);
 
 }  // namespace gpv

@@ -500,10 +500,12 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     double *ac = L.acc[sub];
                     if (fail) {
                         ac[6] += 1.0;
+                        if (A.aout != nullptr) A.aout[A.rowid[k]] = 0.0;
                     } else {
                         const double tau = nugraw[q];
                         const double tv = tau + vlast;
                         const double rz = zi[q] + negmu;             // z_k - mu_k
+                        if (A.aout != nullptr) A.aout[A.rowid[k]] = negmu * rs;
                         if (A.flags & 2) {
                             ac[2] += log(tv);
                             ac[3] += rz * rz / tv;

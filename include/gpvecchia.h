@@ -43,7 +43,9 @@ enum {
 enum {
     GPV_WANT_U = 1,        /* materialise Lentries (the U factor entries) in HBM              */
     GPV_WANT_LOGLIK_Z = 2, /* fused cond.yz='z' log-likelihood sums (needs gpv_plan_set_data) */
-    GPV_WANT_NUMERATOR = 4 /* numerator sums of R/vecchia_likelihood.R:74-76 for any cond.yz  */
+    GPV_WANT_NUMERATOR = 4,/* numerator sums of R/vecchia_likelihood.R:74-76 for any cond.yz  */
+    GPV_WANT_DENOM = 8     /* + posterior pass (U2V) on the GPU for cond.yz='SGV': sums[2] = log det W, sums[3] = quadform.denom
+                              (R/vecchia_likelihood.R:85-90); needs gpv_plan_build_posterior; implies WANT_U|WANT_NUMERATOR */
 };
 
 /* layout of the 8-double partial-sum vector produced by an eval (summed over the
@@ -54,6 +56,7 @@ enum {
  *   [3] sum_k (z_k - mu_k)^2/(tau_k+v_k), mu_k = -a_k/d_k                       (cond.yz='z' only)
  *   [4] sum_k z_k^2 / tau_k        (observed columns of z1, :74-75)
  *   [5] sum_k log tau_k
+ *   with GPV_WANT_DENOM slots [2],[3] hold instead  log det W  and  z2' W^{-1} z2  (W = U_y U_y^T)
  *   [6] number of rows whose block was not positive definite
  *   [7] number of rows processed
  */
@@ -141,6 +144,13 @@ int gpv_plan_set_data(gpv_plan *plan, const double *z_ord);
 int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms,
                   const double *nuggets, int64_t n_nuggets, int flags, void *stream, double *d_sums_out);
 
+/* Posterior ("U2V") structure for cond.yz='SGV' (R/vecchia_prediction.R:62-83): column/row lists of the latent
+ * block of U and a level schedule, from the same revNNarray / revCondOnLatent handed to gpv_plan_create.
+ * Requires a plan that owns all rows.  For SGV the factor has no fill, so the fixed-pattern factorisation is
+ * exact; for other conditioning patterns it is the zero-fill incomplete factor (the reference's ic0=TRUE). */
+int gpv_plan_build_posterior(gpv_plan *plan, const int *revNNarray, const int *revCondOnLatent);
+int gpv_plan_posterior_levels(gpv_plan *plan, int *n_levels);
+
 /* blocking getters (synchronise the eval's stream first) */
 int gpv_plan_get_sums(gpv_plan *plan, double *sums /* GPV_NSUMS */);
 int gpv_plan_get_Lentries(gpv_plan *plan, double *Lentries /* (row_end-row_begin) x ncolNN col-major */);
@@ -154,6 +164,8 @@ int gpv_plan_last_kernel_ms(gpv_plan *plan, double *ms);
 /* cond.yz='z' log-likelihood from the (all-reduced) sums; n = number of observations.
  * Closed form of R/vecchia_likelihood.R:63-99 when W = U_y U_y^T is diagonal. */
 int gpv_loglik_z_from_sums(const double *sums, int64_t n, double *loglik);
+/* general form of R/vecchia_likelihood.R:95-96 from sums produced with GPV_WANT_DENOM */
+int gpv_loglik_from_sums(const double *sums, int64_t n, double *loglik);
 /* numerator pieces of R/vecchia_likelihood.R:74-76: logdet.num, quadform.num */
 int gpv_numerator_from_sums(const double *sums, double *logdet_num, double *quadform_num);
 

@@ -284,6 +284,39 @@ def test_general_nu_through_the_hot_path(nu, cond):
     assert abs(G.vecchia_likelihood(z, pva, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)
 
 
+@pytest.mark.parametrize("n,m,d,ordering", [(400, 8, 2, "maxmin"), (1500, 20, 2, "none"), (900, 30, 2, "maxmin"),
+                                             (700, 12, 3, "none"), (300, 5, 1, "coord")])
+def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
+    # default cond.yz='SGV': U, numerator and the posterior pass (U2V: R/vecchia_prediction.R:62-83) on the GPU
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(n + m)
+    locs = rng.random((n, d)); z = rng.standard_normal(n)
+    cp = [1.4, 0.15 if d > 1 else 0.004, 1.5]
+    tau = 0.1 + 0.2 * rng.random(n)                                   # per-observation nuggets
+    vb = R.vecchia_specify(locs, m, ordering=ordering, cond_yz="SGV")
+    refU = R.createU(vb, cp, tau)
+    ll_ref = R.vecchia_likelihood_U(z, refU)
+    va = G.vecchia_specify(locs, m, ordering=ordering, cond_yz="SGV")
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    plan = va[("_plan", 0)]
+    assert plan.has_posterior                                          # the device path ran, not the host fallback
+    assert abs(ll - ll_ref) <= LL_RTOL * abs(ll_ref)
+    # pieces: log det W and z2' W^{-1} z2 against the dense restatement
+    s = plan.sums()
+    U, lat = refU["U"], refU["latent"]
+    Uy = U[lat, :]
+    W = Uy @ Uy.T
+    z1 = U[~lat, :].T @ z[vb["ord_z"] - 1]
+    z2 = Uy @ z1
+    np.testing.assert_allclose(s[2], np.linalg.slogdet(W)[1], rtol=1e-9)
+    np.testing.assert_allclose(s[3], z2 @ np.linalg.solve(W, z2), rtol=1e-7)
+    # scalar nugget path and the host (scipy) fallback agree with the device path
+    ll2 = G.vecchia_likelihood(z, va, cp, 0.1)
+    U_obj = G.createU(va, cp, 0.1)
+    assert abs(ll2 - G.vecchia_likelihood_U(z, U_obj)) <= 1e-9 * abs(ll2)
+
+
 def test_m_equals_n_minus_1_exact_density():
     # vignette identity on the GPU path: m = n-1 => exact multivariate normal log density
     G = _need_gpu()
