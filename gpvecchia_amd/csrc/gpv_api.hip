@@ -473,6 +473,16 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
             }
         }
         colptr[(size_t)k + 1] = (int32_t)crow.size();
+        {   // ascending rows within the column (insertion sort, <= 64 entries); self = k is the maximum, stays last
+            const size_t b0 = (size_t)colptr[(size_t)k], e0 = crow.size();
+            for (size_t a = b0 + 1; a < e0; ++a) {
+                const int32_t rv = crow[a];
+                const uint8_t sv = cslot[a];
+                size_t b = a;
+                while (b > b0 && crow[b - 1] > rv) { crow[b] = crow[b - 1]; cslot[b] = cslot[b - 1]; --b; }
+                crow[b] = rv; cslot[b] = sv;
+            }
+        }
     }
     const size_t nnz = crow.size();
     std::vector<int32_t> rowptr((size_t)n + 1, 0);

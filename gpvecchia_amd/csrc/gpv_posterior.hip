@@ -18,66 +18,141 @@
 
 namespace gpv {
 
-__global__ void __launch_bounds__(256) gpv_posterior_level_kernel(const PostArgs A, int first, int count)
+// Lanes own the COLUMNS c > k of row k's list (64 per round), not the rows of column k: a hub row that is
+// conditioned on by hundreds of later points is then a few wide rounds instead of one long serial merge.
+// For each of its column's entries the lane looks up the matching row of column k (binary search over the
+// wave's registers via ds_bpermute, no memory traffic) and drops the product into an LDS tile T[row][lane];
+// row sums are taken in a fixed order afterwards => bitwise reproducible.
+// WPC = waves cooperating on one column: 1 in the wide early levels (one column per wave, 4 per block),
+// 8 in the narrow tail levels whose columns belong to "hub" points with row lists of hundreds to thousands
+// of entries (the rounds of 64 columns are dealt round-robin to the waves, partial results meet in LDS).
+template <int WPC>
+__global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kernel(const PostArgs A, int first, int count)
 {
+    extern __shared__ double tile_all[];
     const int lane = threadIdx.x & 63;
-    const int w = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
-    if (w >= count) return;
+    const int wib = threadIdx.x >> 6;
+    const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
+    if (WPC == 1 && w >= count) return;
+    const int ld = A.ld;
+    double *T = tile_all + (size_t)wib * ld * 65;
     const int k = A.order[first + w];
     const int cp = A.colptr[k];
-    const int cnt = A.colptr[k + 1] - cp;            // latent entries of column k (self is the last one)
-    const int ld = A.ld;
-    const int qb = A.rowptr[k], qe = A.rowptr[k + 1];
-    const int self_slot = A.cslot[cp + cnt - 1];
-    const double dk = A.L[(int64_t)k * ld + self_slot];
-
-    double acc = 0.0;
-    int slot = 0;
+    const int cnt = A.colptr[k + 1] - cp;            // latent entries of column k, ascending rows, self (= k) last
+    const int qb = A.rowptr[k], qe = A.rowptr[k + 1];  // row list of k: columns ascending, first is k itself
+    int my_row = 0x7fffffff, my_slot = 0;
     if (lane < cnt) {
-        const int i = A.crow[cp + lane];
-        slot = A.cslot[cp + lane];
-        int p = A.rowptr[i];
-        const int pe = A.rowptr[i + 1];
-        int q = qb;
-        // both lists ascend; only columns c > k contribute (c == k is the term B_ik d_k below)
-        while (p < pe && q < qe) {
-            const int ci = A.rcol[p], ck = A.rcol[q];
-            if (ci <= k) { ++p; continue; }
-            if (ck <= k) { ++q; continue; }
-            if (ci < ck) { ++p; }
-            else if (ci > ck) { ++q; }
-            else {
-                const int64_t base = (int64_t)ci * ld;
-                const int si = A.rslot[p], sk = A.rslot[q];
-                acc += A.L[base + si] * A.L[base + sk] - A.R[base + si] * A.R[base + sk];
-                ++p; ++q;
+        my_row = A.crow[cp + lane];
+        my_slot = A.cslot[cp + lane];
+    }
+    const int self_slot = __shfl(my_slot, cnt - 1, 64);
+    const double dk = A.L[(int64_t)k * ld + self_slot];
+    int nsteps = 0;
+    while ((1 << nsteps) < cnt + 1) ++nsteps;        // binary-search depth, wave uniform
+
+    double acc = 0.0, z2 = 0.0, s = 0.0;
+    for (int base = qb + 64 * ((WPC == 1) ? 0 : wib); base < qe; base += 64 * WPC) {
+        const int q = base + lane;
+        const bool active = q < qe;
+        int c = k, sk = 0, cb = 0, cn = 0;
+        double Bk = 0.0, Rk = 0.0;
+        if (active) {
+            c = A.rcol[q];
+            sk = A.rslot[q];
+            const int64_t o = (int64_t)c * ld + sk;
+            Bk = A.L[o];
+            z2 = __builtin_fma(Bk, A.avec[c], z2);
+            if (c > k) {
+                Rk = A.R[o];
+                s = __builtin_fma(Rk, A.tvec[c], s);
+                cb = A.colptr[c];
+                cn = A.colptr[c + 1] - cb;
             }
         }
-        acc = __builtin_fma(A.L[(int64_t)k * ld + slot], dk, acc);
-    }
-    // diagonal: the self lane (cnt-1) holds sum (B_kc^2 - R_kc^2) + d_k^2
-    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
-    const double accd = __shfl(acc, cnt - 1, 64) + 1.0 / tau;
-    const double rkk = sqrt(accd);
-    if (lane < cnt) A.R[(int64_t)k * ld + slot] = (lane == cnt - 1) ? rkk : acc / rkk;
-
-    // row k of R and B is complete: z2_k and the triangular solve (lanes stride over the row list, then reduce)
-    double z2 = 0.0, s = 0.0;
-    for (int q = qb + lane; q < qe; q += 64) {
-        const int c = A.rcol[q];
-        const int64_t base = (int64_t)c * ld + A.rslot[q];
-        z2 = __builtin_fma(A.L[base], A.avec[c], z2);
-        if (c > k) s = __builtin_fma(A.R[base], A.tvec[c], s);
+        for (int t = 0; t < cnt; ++t) T[t * 65 + lane] = 0.0;
+        int maxcn = cn;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int o2 = __shfl_xor(maxcn, off, 64);
+            maxcn = o2 > maxcn ? o2 : maxcn;
+        }
+        // the lane's column c is consumed in bursts of EC entries: all loads of a burst are independent and
+        // issued together (row ids, then slots/values of the matches), the binary searches in between are ALU only
+        constexpr int EC = 8;
+        for (int e0 = 0; e0 < maxcn; e0 += EC) {
+            int r[EC], pos[EC];
+#pragma unroll
+            for (int u = 0; u < EC; ++u) r[u] = (e0 + u < cn) ? A.crow[cb + e0 + u] : -1;
+#pragma unroll
+            for (int u = 0; u < EC; ++u) {
+                int lo = 0, hi = cnt;
+                for (int st = 0; st < nsteps; ++st) {
+                    const int mid = (lo + hi) >> 1;
+                    const int v = __shfl(my_row, mid < cnt ? mid : cnt - 1, 64);
+                    const bool go = (lo < hi) && (v < r[u]);
+                    const bool stay = (lo < hi) && !(v < r[u]);
+                    lo = go ? mid + 1 : lo;
+                    hi = stay ? mid : hi;
+                }
+                const int v = __shfl(my_row, lo < cnt ? lo : cnt - 1, 64);
+                pos[u] = (r[u] >= 0 && lo < cnt && v == r[u]) ? lo : -1;
+            }
+            double lv[EC], rv[EC];
+#pragma unroll
+            for (int u = 0; u < EC; ++u) {
+                lv[u] = 0.0; rv[u] = 0.0;
+                if (pos[u] >= 0) {
+                    const int64_t o = (int64_t)c * ld + A.cslot[cb + e0 + u];
+                    lv[u] = A.L[o];
+                    rv[u] = A.R[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < EC; ++u)
+                if (pos[u] >= 0) T[pos[u] * 65 + lane] = lv[u] * Bk - rv[u] * Rk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < cnt) {
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;       // fixed association => reproducible
+            for (int l = 0; l < 64; l += 4) {
+                r0 += T[lane * 65 + l];
+                r1 += T[lane * 65 + l + 1];
+                r2 += T[lane * 65 + l + 2];
+                r3 += T[lane * 65 + l + 3];
+            }
+            acc += (r0 + r1) + (r2 + r3);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         z2 += __shfl_down(z2, off, 64);
         s += __shfl_down(s, off, 64);
     }
+    if constexpr (WPC > 1) {
+        // combine the waves' partial results in wave order (fixed => reproducible)
+        __shared__ double part[WPC][66];
+        part[wib][lane] = acc;
+        if (lane == 0) { part[wib][64] = z2; part[wib][65] = s; }
+        __syncthreads();
+        if (wib != 0) return;
+        acc = 0.0; z2 = 0.0; s = 0.0;
+        for (int v = 0; v < WPC; ++v) {
+            acc += part[v][lane];
+            z2 += part[v][64];
+            s += part[v][65];
+        }
+    }
+    if (lane < cnt) acc = __builtin_fma(A.L[(int64_t)k * ld + my_slot], dk, acc);      // c == k term: B_ik d_k
+    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
+    const double accd = __shfl(acc, cnt - 1, 64) + 1.0 / tau;
+    const double rkk = sqrt(accd);
+    if (lane < cnt) A.R[(int64_t)k * ld + my_slot] = (lane == cnt - 1) ? rkk : acc / rkk;
     if (lane == 0) {
         z2 -= A.z[k] / tau;                          // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
-        const double t = (z2 - s) / rkk;
-        A.tvec[k] = t;
+        A.tvec[k] = (z2 - s) / rkk;
         A.logr[k] = log(rkk);
     }
 }
@@ -85,8 +160,20 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_kernel(const PostArgs
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
-    const int wpb = 4;
-    hipLaunchKernelGGL(gpv_posterior_level_kernel, dim3((count + wpb - 1) / wpb), dim3(wpb * 64), 0, s, a, first, count);
+    if (count <= 128 && a.ld <= 32) {                 // narrow tail level: 8 waves per column
+        const size_t smem = (size_t)8 * a.ld * 65 * sizeof(double);
+        static bool attr_set = false;
+        if (!attr_set) {                              // > 64 KiB of dynamic LDS needs the opt-in
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(gpv_posterior_level_kernel<8>, dim3(count), dim3(512), smem, s, a, first, count);
+        return hipGetLastError();
+    }
+    const int wpb = a.ld <= 32 ? 4 : 2;
+    const size_t smem = (size_t)wpb * a.ld * 65 * sizeof(double);
+    hipLaunchKernelGGL(gpv_posterior_level_kernel<1>, dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count);
     return hipGetLastError();
 }
 

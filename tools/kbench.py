@@ -45,9 +45,32 @@ def child(args):
                 if it >= 2:
                     ts.append(plan.last_kernel_ms())
             out[mode] = round(float(np.median(ts)), 4)
-        out["loglik"] = G.loglik_z_from_sums(s, n) if False else None
         res[cfg] = out
         del plan
+        if args.sgv and m <= 32:
+            import time
+            t0 = time.time()
+            cond = S.whichCondOnLatent(NN)
+            t_cond = time.time() - t0
+            rc = cond[:, ::-1].copy()
+            plan = G.Plan(locs, revNN, rc)
+            t0 = time.time()
+            nlev = plan.build_posterior()
+            t_build = time.time() - t0
+            plan.set_data(np.random.default_rng(1).standard_normal(n))
+            ts = []
+            for it in range(args.iters + 2):
+                t0 = time.time()
+                plan.eval("matern", cp, 0.1, G.GPV_WANT_DENOM)
+                s = plan.sums()
+                if it >= 2:
+                    ts.append((time.time() - t0) * 1e3)
+            out["SGV_eval_wall_ms"] = round(float(np.median(ts)), 3)
+            out["SGV_sets_kernel_ms"] = round(plan.last_kernel_ms(), 3)
+            out["SGV_levels"] = nlev
+            out["SGV_setup_s"] = [round(t_cond, 1), round(t_build, 2)]
+            out["SGV_loglik"] = G.loglik_from_sums(s, n)
+            del plan
     print("KBENCH " + json.dumps(res), flush=True)
 
 
@@ -58,6 +81,7 @@ if __name__ == "__main__":
     ap.add_argument("--configs", default="30x2,20x2,60x3,10x2")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--child", action="store_true")
+    ap.add_argument("--sgv", action="store_true")
     a = ap.parse_args()
     if a.child:
         child(a)
@@ -66,6 +90,6 @@ if __name__ == "__main__":
         for lib in libs:
             env = dict(os.environ, GPV_LIB=os.path.abspath(lib))
             r = subprocess.run([sys.executable, __file__, "--child", "--n", str(a.n), "--configs", a.configs,
-                                "--iters", str(a.iters)], env=env, capture_output=True, text=True)
+                                "--iters", str(a.iters)] + (["--sgv"] if a.sgv else []), env=env, capture_output=True, text=True)
             line = [l for l in r.stdout.splitlines() if l.startswith("KBENCH")]
             print(os.path.basename(lib), line[0] if line else ("FAILED\n" + r.stdout[-2000:] + r.stderr[-2000:]), flush=True)
