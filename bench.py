@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 #   n0*(4 B index + 1 B cond flag) + 8*d coords + 8 nugget + 8 z  + 16 B of partial sums
 # flop model of SURVEY.md §8d: p^3/3 + p^2 + p(p-1)/2 * (3d + 25)
 def alg_bytes_per_set(p, d, mode):
-    out = 8 * p if mode == "U" else 16
+    out = 8 * p if mode in ("U", "S") else 16
     return p * 5 + 8 * d + 8 + 8 + out
 
 
@@ -43,7 +43,7 @@ def flops_per_set(p, d):
     return p ** 3 / 3.0 + p ** 2 + 0.5 * p * (p - 1) * (3 * d + 25)
 
 
-def build_workload(n, m, d, rank, world, seed=0):
+def build_workload(n, m, d, rank, world, seed=0, sgv=False):
     from gpvecchia_amd import specify as S
     rng = np.random.default_rng(seed)
     locs = rng.random((n, d))
@@ -52,8 +52,11 @@ def build_workload(n, m, d, rank, world, seed=0):
     b = ((rank + 1) * n) // world
     NN = S.find_ordered_nn(locs, m, rows=(a, b))          # only this rank's rows are searched
     revNN = NN[:, ::-1].copy()
-    revCond = np.where(revNN != 0, 0, -1).astype(np.int8)  # cond.yz='z' (R/vecchia_specify.R:189-190)
-    revCond[:, -1] = 1
+    if sgv:
+        revCond = S.whichCondOnLatent(NN)[:, ::-1].copy()   # cond.yz='SGV' (R/vecchia_specify.R:182-183)
+    else:
+        revCond = np.where(revNN != 0, 0, -1).astype(np.int8)  # cond.yz='z' (R/vecchia_specify.R:189-190)
+        revCond[:, -1] = 1
     return locs, z, revNN, revCond, a, b
 
 
@@ -99,8 +102,9 @@ def main():
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--m", type=int, default=30)
     ap.add_argument("--d", type=int, default=2)
-    ap.add_argument("--mode", choices=["L", "U"], default="L",
-                    help="L: fused log-likelihood (headline); U: also materialise the U entries in HBM")
+    ap.add_argument("--mode", choices=["L", "U", "S"], default="L",
+                    help="L: fused log-likelihood, cond.yz='z' (headline); U: also materialise the U entries in HBM; "
+                         "S: the reference's default cond.yz='SGV' with the posterior pass (U2V) on the GPU, 1 GPU only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="conditioning sets in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -127,12 +131,18 @@ def main():
     covparms = [1.0, 0.02 if d == 2 else 0.05, 1.5]
     tau = 0.1
     t_setup = time.time()
-    locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world)
+    if args.mode == "S" and world > 1:
+        raise SystemExit("mode S (SGV posterior pass) does not shard: replicas only (DESIGN.md §6)")
+    locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, sgv=(args.mode == "S"))
     plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
     plan.set_data(z)
+    if args.mode == "S":
+        plan.build_posterior()
     t_setup = time.time() - t_setup
 
     flags = G.GPV_WANT_LOGLIK_Z | (G.GPV_WANT_U if args.mode == "U" else 0)
+    if args.mode == "S":
+        flags = G.GPV_WANT_DENOM
     sums = torch.zeros(G._lib.NSUMS, dtype=torch.float64, device="cuda")
     # one explicit (non-null) HIP stream carries the kernel, the all-reduce and the D2H copy of every step;
     # a NULL handle would select the plan's private stream and un-order the consumers below
@@ -145,7 +155,8 @@ def main():
         plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
         if world > 1:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM)       # the ONE collective: 64 bytes over xGMI
-        return G.loglik_z_from_sums(sums.cpu().numpy(), n)    # scalar on the host (implicit stream sync)
+        host = sums.cpu().numpy()                             # scalar on the host (implicit stream sync)
+        return G.loglik_from_sums(host, n) if args.mode == "S" else G.loglik_z_from_sums(host, n)
 
     def fence():
         torch.cuda.synchronize()
@@ -192,7 +203,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"n={n} {d}-D uniform, Matern nu=1.5, m={m}, cond.yz=z, mode {args.mode} "
+            "config": {"workload": f"n={n} {d}-D uniform, Matern nu=1.5, m={m}, cond.yz={'SGV' if args.mode == 'S' else 'z'}, mode {args.mode} "
                                    f"(BASELINE.json configs[2] geometry; rows sharded over {world} GPU(s))",
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
                        "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2)},
