@@ -20,6 +20,7 @@ GPV_WANT_U = 1
 GPV_WANT_LOGLIK_Z = 2
 GPV_WANT_NUMERATOR = 4
 GPV_WANT_DENOM = 8
+GPV_WANT_MEAN = 16
 
 # every symbol include/gpvecchia.h declares (tests check the library exports all of them)
 EXPORTS = [
@@ -29,7 +30,7 @@ EXPORTS = [
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
     "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
-    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums",
+    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean",
 ]
 
 
@@ -80,6 +81,7 @@ def lib():
     L.gpv_numerator_from_sums.argtypes = [dp, dp, dp]
     L.gpv_plan_build_posterior.argtypes = [vp, ip, ip]
     L.gpv_plan_posterior_levels.argtypes = [vp, ip]
+    L.gpv_plan_get_posterior_mean.argtypes = [vp, dp]
     L.gpv_loglik_from_sums.argtypes = [dp, i64, dp]
     L.gpv_whichCondOnLatent.argtypes = [ip, i64, C.c_int, i64, ip]
     _lib = L

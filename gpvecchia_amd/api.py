@@ -96,6 +96,12 @@ class Plan:
         L.check(L.lib().gpv_plan_Lentries_device(self._h, C.byref(ptr), C.byref(ld)), "gpv_plan_Lentries_device")
         return ptr.value, int(ld.value)
 
+    def posterior_mean(self):
+        """mu.ord of R/vecchia_prediction.R:118-126 after an eval with GPV_WANT_MEAN."""
+        out = np.zeros(self.Nlocs)
+        L.check(L.lib().gpv_plan_get_posterior_mean(self._h, L.dptr(out)), "gpv_plan_get_posterior_mean")
+        return out
+
     def last_kernel_ms(self):
         ms = C.c_double()
         L.check(L.lib().gpv_plan_last_kernel_ms(self._h, C.byref(ms)), "gpv_plan_last_kernel_ms")
@@ -359,6 +365,17 @@ def U2V(U_obj):
     rev = np.arange(nW - 1, -1, -1)
     Wrev = W[rev][:, rev].tocsc()
     return spla.splu(Wrev, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+
+
+def vecchia_mean_host(z, U_obj):
+    """R/vecchia_prediction.R:118-126 on the host (sparse LU of W.rev): mu.ord = -W^{-1} z2."""
+    U = U_obj["U"].tocsr()
+    latent = U_obj["latent"]
+    zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]
+    z1 = U[np.where(~latent)[0], :].T @ zord
+    z2 = U[np.where(latent)[0], :] @ z1
+    lu = U2V(U_obj)
+    return -(lu.solve(z2[::-1]))[::-1]
 
 
 def vecchia_likelihood_U(z, U_obj):

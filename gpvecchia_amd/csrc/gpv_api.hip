@@ -117,7 +117,10 @@ struct gpv_plan {
     uint8_t *d_cslot = nullptr, *d_rslot = nullptr;
     double *d_R = nullptr, *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
            *d_post2 = nullptr, *d_zuser = nullptr;
-    std::vector<int32_t> levptr;
+    std::vector<int32_t> levptr, levptr2;
+    int32_t *d_order2 = nullptr;
+    double *d_u = nullptr, *d_mu = nullptr;
+    bool have_mean = false;
     double nug_scalar = 0.0;
     bool nug_is_scalar = true;
     uint8_t *d_cond = nullptr;
@@ -167,7 +170,8 @@ int gpv_plan_destroy(gpv_plan *pl)
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_rowptr, pl->d_rcol, pl->d_order, pl->d_cslot, pl->d_rslot,
-                    pl->d_R, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser};
+                    pl->d_R, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser,
+                    pl->d_order2, pl->d_u, pl->d_mu};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -357,6 +361,7 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
 static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nuggets, int64_t n_nuggets, int flags,
                           void *stream_v, double *d_sums_out)
 {
+    if (flags & GPV_WANT_MEAN) flags |= GPV_WANT_DENOM;
     if (flags & GPV_WANT_DENOM) {
         if (!pl->have_post) return GPV_ERR_STATE;
         flags |= GPV_WANT_U | GPV_WANT_NUMERATOR;
@@ -420,6 +425,12 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], st));
         GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_post2, st));
         GPV_HIP(launch_patch_denominator(pl->d_post2, pl->d_sums, d_sums_out, st));
+        if (flags & GPV_WANT_MEAN) {
+            for (size_t lv = 0; lv + 1 < pl->levptr2.size(); ++lv)
+                GPV_HIP(launch_mean_level(pa, pl->d_order2, pl->d_u, pl->levptr2[lv], pl->levptr2[lv + 1] - pl->levptr2[lv], st));
+            GPV_HIP(launch_negate(pl->d_u, pl->d_mu, pl->Nlocs, st));
+            pl->have_mean = true;
+        }
     }
     pl->evaluated = true;
     pl->have_U = (flags & GPV_WANT_U) != 0;
@@ -514,6 +525,24 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     std::vector<int32_t> pos(pl->levptr.begin(), pl->levptr.end() - 1), order((size_t)n);
     for (int64_t k = n - 1; k >= 0; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
 
+    // second schedule for the posterior mean (R^T u = t): column k waits for the rows i < k it contains
+    std::vector<int32_t> lev2((size_t)n, 0);
+    int32_t maxlev2 = 0;
+    for (int64_t k = 0; k < n; ++k) {
+        int32_t l = 0;
+        for (int32_t e = colptr[(size_t)k]; e < colptr[(size_t)k + 1]; ++e) {
+            const int32_t i = crow[(size_t)e];
+            if (i < (int32_t)k && lev2[(size_t)i] + 1 > l) l = lev2[(size_t)i] + 1;
+        }
+        lev2[(size_t)k] = l;
+        if (l > maxlev2) maxlev2 = l;
+    }
+    pl->levptr2.assign((size_t)maxlev2 + 2, 0);
+    for (int64_t k = 0; k < n; ++k) pl->levptr2[(size_t)lev2[(size_t)k] + 1]++;
+    for (int32_t l = 0; l <= maxlev2; ++l) pl->levptr2[(size_t)l + 1] += pl->levptr2[(size_t)l];
+    std::vector<int32_t> pos2(pl->levptr2.begin(), pl->levptr2.end() - 1), order2((size_t)n);
+    for (int64_t k = 0; k < n; ++k) order2[(size_t)pos2[(size_t)lev2[(size_t)k]]++] = (int32_t)k;
+
     GPV_HIP(hipSetDevice(pl->device));
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
@@ -529,15 +558,28 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if ((rc = up((void **)&pl->d_rcol, rcol.data(), nnz * 4)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_rslot, rslot.data(), nnz)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_order, order.data(), order.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     const size_t nd = sizeof(double) * (size_t)n;
     if (!pl->d_R) GPV_HIP(hipMalloc((void **)&pl->d_R, nd * pl->P));
     if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
     if (!pl->d_tvec) GPV_HIP(hipMalloc((void **)&pl->d_tvec, nd));
     if (!pl->d_logr) GPV_HIP(hipMalloc((void **)&pl->d_logr, nd));
+    if (!pl->d_u) GPV_HIP(hipMalloc((void **)&pl->d_u, nd));
+    if (!pl->d_mu) GPV_HIP(hipMalloc((void **)&pl->d_mu, nd));
     if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 512));
     if (!pl->d_post2) GPV_HIP(hipMalloc((void **)&pl->d_post2, sizeof(double) * 2));
     if (!pl->d_L) GPV_HIP(hipMalloc((void **)&pl->d_L, nd * pl->P));
     pl->have_post = true;
+    return GPV_OK;
+}
+
+int gpv_plan_get_posterior_mean(gpv_plan *pl, double *mu_ord)
+{
+    if (!pl || !mu_ord) return GPV_ERR_BAD_ARG;
+    if (!pl->evaluated || !pl->have_mean) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    GPV_HIP(hipMemcpyAsync(mu_ord, pl->d_mu, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyDeviceToHost, pl->last_stream));
+    GPV_HIP(hipStreamSynchronize(pl->last_stream));
     return GPV_OK;
 }
 

@@ -177,6 +177,46 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipSt
     return hipGetLastError();
 }
 
+// ---- posterior mean: R^T u = t, one wavefront per column, lanes = entries of the (short) column ------------
+__global__ void __launch_bounds__(256) gpv_mean_level_kernel(const PostArgs A, const int32_t *order2, double *u, int first,
+                                                             int count)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = (blockIdx.x * (blockDim.x >> 6)) + (threadIdx.x >> 6);
+    if (w >= count) return;
+    const int k = order2[first + w];
+    const int cp = A.colptr[k];
+    const int cnt = A.colptr[k + 1] - cp;            // rows ascending, self last
+    double part = 0.0, rkk = 1.0;
+    if (lane < cnt) {
+        const int i = A.crow[cp + lane];
+        const double r = A.R[(int64_t)k * A.ld + A.cslot[cp + lane]];
+        if (lane == cnt - 1) rkk = r; else part = r * u[i];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+    rkk = __shfl(rkk, cnt - 1, 64);
+    if (lane == 0) u[k] = (A.tvec[k] - part) / rkk;
+}
+hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u, int first, int count, hipStream_t s)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gpv_mean_level_kernel, dim3((count + 3) / 4), dim3(256), 0, s, a, order2, u, first, count);
+    return hipGetLastError();
+}
+__global__ void gpv_negate_kernel(const double *src, double *dst, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = -src[i];
+}
+hipError_t launch_negate(const double *src, double *dst, int64_t n, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gpv_negate_kernel, dim3(grid), dim3(256), 0, s, src, dst, n);
+    return hipGetLastError();
+}
+
 // ---- deterministic pair reduction: out[0] = sum x, out[1] = sum y^2 ------------------------------------
 __global__ void __launch_bounds__(256) gpv_sum_pair_stage1(const double *x, const double *y, int64_t n, double *partials)
 {

@@ -1,0 +1,156 @@
+"""Vecchia-Laplace approximation for non-Gaussian data — host-side mirror of
+R/vecchia_laplace_NR.R (calculate_posterior_VL :31-155, likelihood families :213-322,
+vecchia_laplace_likelihood :361-416) and of the mean part of vecchia_prediction
+(R/vecchia_prediction.R:17-56,118-142).
+
+Every Newton-Raphson step is one vecchia_prediction(..., return.values='meanmat') with
+per-observation pseudo-nuggets: on the GPU that is one conditioning-set launch (the hot path,
+vector nuggets) plus the posterior pass (U2V) and the two triangular solves of vecchia_mean.
+The O(n) family functions (score, Hessian, link) stay on the host.
+"""
+from __future__ import annotations
+
+import warnings
+
+import numpy as np
+
+from . import api as A
+from ._lib import GPV_WANT_MEAN
+
+
+# ---------------------------------------------------------------------------
+# likelihood families — R/vecchia_laplace_NR.R:213-322
+# ---------------------------------------------------------------------------
+def _families(model, likparms):
+    from scipy.special import betaln, digamma, gammaln, polygamma
+    alpha = float(likparms.get("alpha", 2))
+    sigma = float(likparms.get("sigma", np.sqrt(.1)))
+    beta = float(likparms.get("beta", .5))
+    if model == "gaussian":                                               # :246-253
+        return dict(hess=lambda y, z: np.full(len(y), 1 / sigma ** 2), score=lambda y, z: (z - y) / sigma ** 2,
+                    llh=lambda y, z: np.sum(-.5 * (z - y) ** 2 / sigma ** 2) - len(y) * (np.log(sigma) + np.log(2 * np.pi) / 2),
+                    link=lambda y: y, bad=lambda z: False)
+    if model == "logistic":                                               # :213-223
+        return dict(hess=lambda y, z: np.exp(y) / (1 + np.exp(y)) ** 2, score=lambda y, z: z - np.exp(y) / (1 + np.exp(y)),
+                    llh=lambda y, z: np.sum(z * y - np.log(1 + np.exp(y))), link=lambda y: np.exp(y) / (1 + np.exp(y)),
+                    bad=lambda z: not np.all(np.isin(z, (0, 1))))
+    if model == "poisson":                                                # :225-237
+        return dict(hess=lambda y, z: np.exp(y), score=lambda y, z: z - np.exp(y),
+                    llh=lambda y, z: np.sum(z * y - np.exp(y) - gammaln(z + 1)), link=lambda y: np.exp(y),
+                    bad=lambda z: bool(np.any(z < 0) or np.any(z % 1 > 0)))
+    if model == "gamma":                                                  # :266-276
+        return dict(hess=lambda y, z: alpha * z * np.exp(-y), score=lambda y, z: alpha * (z * np.exp(-y) - 1),
+                    llh=lambda y, z: np.sum(-alpha * z * np.exp(-y) + (alpha - 1) * np.log(z) - alpha * y
+                                            + alpha * np.log(alpha) - gammaln(alpha)),
+                    link=lambda y: np.exp(y), bad=lambda z: bool(np.any(z <= 0)))
+    if model == "gamma_alt":                                              # :255-263
+        return dict(hess=lambda y, z: z * np.exp(y), score=lambda y, z: -z * np.exp(y) + alpha,
+                    llh=lambda y, z: np.sum(-np.exp(y) * z + (alpha - 1) * np.log(z) + alpha * y - gammaln(alpha)),
+                    link=lambda y: alpha / np.exp(y), bad=lambda z: bool(np.any(z <= 0)))
+    if model == "beta":                                                   # :283-295
+        def hess(y, z):
+            e = np.exp(y) * beta
+            return (-e * (np.log(z) - digamma(e) + digamma(beta * (1 + np.exp(y))))
+                    - e ** 2 * (-polygamma(1, e) + polygamma(1, beta * (1 + np.exp(y)))))
+        return dict(hess=hess,
+                    score=lambda y, z: np.exp(y) * beta * (np.log(z) - digamma(np.exp(y) * beta) + digamma(beta * (1 + np.exp(y)))),
+                    llh=lambda y, z: np.sum((np.exp(y) * beta - 1) * np.log(z) + (beta - 1) * np.log(1 - z)
+                                            - betaln(beta * np.exp(y), beta)),
+                    link=lambda y: 1 / (1 + np.exp(-y)), bad=lambda z: bool(np.any(z < 0) or np.any(z > 1)))
+    raise ValueError(f"'arg' should be one of gaussian, logistic, poisson, gamma, beta, gamma_alt (got {model})")
+
+
+# ---------------------------------------------------------------------------
+# posterior mean — R/vecchia_prediction.R:17-56 (mean part), :118-142
+# ---------------------------------------------------------------------------
+def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", return_values="mean", device=0):
+    """Posterior mean of the latent field at the observed locations (mu.obs, original order).
+    Variances (SelInv) and prediction locations are not built yet."""
+    va = vecchia_approx
+    z, nug = A._removeNAs(z, nuggets)
+    n = int(np.sum(va["obs"]))
+    if va["cond_yz"] in ("SGV", "z", "false") and isinstance(covmodel, str) and not np.any(nug == 0):
+        plan = A._plan_for(va, device)
+        if not plan.has_posterior:
+            plan.build_posterior()
+        plan.set_data(z[va["ord_z"] - 1])
+        nug_all_ord, _, nugf = A._ordered_nuggets(va, nug, n)
+        plan.eval(covmodel, covparms, nug_all_ord if nugf.size > 1 and not np.all(nugf == nugf[0]) else nugf[:1],
+                  GPV_WANT_MEAN)
+        mu_ord = plan.posterior_mean()
+    else:
+        U_obj = A.createU(va, covparms, nug, covmodel, device=device)
+        mu_ord = A.vecchia_mean_host(z, U_obj)
+    mu = np.empty(n)
+    mu[va["ord"] - 1] = mu_ord                                            # orig.order = order(U.obj$ord), :135-136
+    return dict(mu_obs=mu, mu_pred=np.empty(0), var_obs=None, var_pred=None)
+
+
+# ---------------------------------------------------------------------------
+# Newton-Raphson — R/vecchia_laplace_NR.R:31-155
+# ---------------------------------------------------------------------------
+def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covparms=None, covmodel="matern",
+                           likparms=None, max_iter=50, convg=1e-6, y_init=None, prior_mean=None, verbose=False,
+                           device=0):
+    z = np.asarray(z, dtype=np.float64)
+    likparms = dict(alpha=2, sigma=np.sqrt(.1)) if likparms is None else dict(likparms)
+    if covmodel == "matern" and len(covparms) != 3:
+        raise ValueError(f"Matern kernel requires 3 parameters but {len(covparms)} were passed")   # :39-41
+    if np.any(np.isnan(z)):
+        raise NotImplementedError("missing observations in the VL loop are not built yet")
+    fam = _families(likelihood_model, likparms)
+    if fam["bad"](z):
+        raise ValueError("Data invalid for likelihood type. Make sure that your data lies in the support of the "
+                         "likelihood function.")                                                    # :52-54
+    prior_mean = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64)
+    y_o = prior_mean.copy() if y_init is None or np.any(np.isnan(y_init)) else np.asarray(y_init, float).copy()   # :81-84
+    convgd, tot_iters = False, 0
+    pseudo, D, preds = None, None, None
+    for i in range(1, max_iter + 1):                                      # :88
+        y_prev = y_o
+        D_inv = fam["hess"](y_o, z)                                       # :93
+        if np.any(D_inv < 0):
+            raise ValueError("Negative variances occurred, check parameters")   # :95-98
+        D = 1 / D_inv
+        u = fam["score"](y_o, z)
+        if np.any(~np.isfinite(u)):
+            raise ValueError("Derivative of the loglikehood is infinite. Try different parameter values")   # :102
+        pseudo = D * u + y_o - prior_mean                                 # :105
+        preds = vecchia_prediction(pseudo, vecchia_approx, covparms, D, covmodel, device=device)   # :112-113
+        y_o = preds["mu_obs"] + prior_mean                                # :115
+        dmax = np.max(np.abs(y_o - y_prev))
+        if np.isnan(dmax):                                                # :117-123
+            if verbose:
+                print(f"VL-NR hit NA on iteration {tot_iters}, convergence failed.")
+            y_o = y_prev
+            break
+        if dmax < convg:                                                  # :124-128
+            convgd, tot_iters = True, i
+            break
+        tot_iters += 1
+    return dict(mean=preds["mu_obs"] + prior_mean, cnvgd=convgd, iter=tot_iters, t=pseudo + prior_mean, D=D,
+                prediction=preds, data_link=fam["link"], model_llh=fam["llh"], prior_mean=prior_mean)
+
+
+# ---------------------------------------------------------------------------
+# R/vecchia_laplace_NR.R:361-416
+# ---------------------------------------------------------------------------
+def vecchia_laplace_likelihood(z, vecchia_approx, likelihood_model, covparms, likparms=None, covmodel="matern",
+                               max_iter=50, convg=1e-5, y_init=None, prior_mean=None, device=0):
+    z = np.asarray(z, dtype=np.float64)
+    post = calculate_posterior_VL(z, vecchia_approx, likelihood_model, covparms, covmodel, likparms, max_iter, convg,
+                                  y_init, prior_mean, device=device)
+    if not post["cnvgd"]:                                                 # :373
+        warnings.warn("Convergence Failed, returning -Inf")
+        return -np.inf
+    pm = post["prior_mean"]
+    z_pseudo = post["t"] - pm                                             # :381
+    nug_pseudo = post["D"]
+    pseudo_marginal = A.vecchia_likelihood(z_pseudo, vecchia_approx, covparms, nug_pseudo, covmodel, device=device)   # :396-397
+    true_llh = post["model_llh"](post["mean"], z)                         # :401-402
+    m = post["mean"] - pm
+    pseudo_cond = np.sum(-0.5 * np.log(2 * np.pi * nug_pseudo) - 0.5 * (z_pseudo - m) ** 2 / nug_pseudo)   # :405 dnorm(log=TRUE)
+    ll = pseudo_marginal - pseudo_cond + true_llh                         # :408-409
+    if y_init is None:
+        return ll
+    return dict(llv=ll, mean=post["mean"])

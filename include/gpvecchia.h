@@ -44,8 +44,10 @@ enum {
     GPV_WANT_U = 1,        /* materialise Lentries (the U factor entries) in HBM              */
     GPV_WANT_LOGLIK_Z = 2, /* fused cond.yz='z' log-likelihood sums (needs gpv_plan_set_data) */
     GPV_WANT_NUMERATOR = 4,/* numerator sums of R/vecchia_likelihood.R:74-76 for any cond.yz  */
-    GPV_WANT_DENOM = 8     /* + posterior pass (U2V) on the GPU for cond.yz='SGV': sums[2] = log det W, sums[3] = quadform.denom
+    GPV_WANT_DENOM = 8,    /* + posterior pass (U2V) on the GPU for cond.yz='SGV': sums[2] = log det W, sums[3] = quadform.denom
                               (R/vecchia_likelihood.R:85-90); needs gpv_plan_build_posterior; implies WANT_U|WANT_NUMERATOR */
+    GPV_WANT_MEAN = 16     /* + posterior mean of the latent field in ORDERED layout, mu.ord of R/vecchia_prediction.R:118-126
+                              (two triangular solves with the posterior factor); implies GPV_WANT_DENOM */
 };
 
 /* layout of the 8-double partial-sum vector produced by an eval (summed over the
@@ -150,6 +152,8 @@ int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, i
  * exact; for other conditioning patterns it is the zero-fill incomplete factor (the reference's ic0=TRUE). */
 int gpv_plan_build_posterior(gpv_plan *plan, const int *revNNarray, const int *revCondOnLatent);
 int gpv_plan_posterior_levels(gpv_plan *plan, int *n_levels);
+/* blocking: mu.ord (length Nlocs, ordered layout) after an eval with GPV_WANT_MEAN */
+int gpv_plan_get_posterior_mean(gpv_plan *plan, double *mu_ord);
 
 /* blocking getters (synchronise the eval's stream first) */
 int gpv_plan_get_sums(gpv_plan *plan, double *sums /* GPV_NSUMS */);

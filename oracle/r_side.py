@@ -477,3 +477,87 @@ def separable_loglik_condz(va, U_entries, z, nuggets):
         s[5] += (d * a - zord[k] / tau[k]) ** 2 / w
     loglik = -0.5 * (-2 * s[0] + s[1] + s[2] + s[3] + s[4] - s[5] + n * np.log(2 * np.pi))
     return loglik, s
+
+
+# ----------------------------------------------------------------------------
+# posterior mean and Vecchia-Laplace (R/vecchia_prediction.R, R/vecchia_laplace_NR.R), dense restatements
+# ----------------------------------------------------------------------------
+def vecchia_mean(z, U_obj, V):
+    """R/vecchia_prediction.R:118-142 (no zero nuggets, all observed): returns mu.obs in original order."""
+    from scipy.linalg import solve_triangular
+    U = U_obj["U"]
+    latent = U_obj["latent"]
+    zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]        # :121
+    z1 = U[~latent, :].T @ zord                                        # :122
+    z2 = U[latent, :] @ z1                                             # :123
+    temp = solve_triangular(V, z2[::-1], lower=True)                   # :124
+    mu_rev = -solve_triangular(V.T, temp, lower=False)                 # :125
+    mu_ord = mu_rev[::-1]                                              # :126
+    orig_order = np.argsort(U_obj["ord"], kind="stable")               # :135
+    return mu_ord[orig_order]                                          # :136-138
+
+
+def vecchia_prediction_mean(z, va, covparms, nuggets, covmodel="matern"):
+    """R/vecchia_prediction.R:17-56 with return.values='meanmat' (mean only)."""
+    U_obj = createU(va, covparms, nuggets, covmodel)                   # :25
+    V = U2V(U_obj)                                                     # :28
+    return vecchia_mean(z, U_obj, V)                                   # :34
+
+
+def vl_family(model, likparms=None):
+    """R/vecchia_laplace_NR.R:213-276."""
+    from scipy.special import gammaln
+    lp = dict(alpha=2, sigma=np.sqrt(.1))
+    lp.update(likparms or {})
+    a, sg = lp["alpha"], lp["sigma"]
+    if model == "poisson":
+        return dict(hess=lambda y, z: np.exp(y), score=lambda y, z: z - np.exp(y),
+                    llh=lambda y, z: np.sum(z * y - np.exp(y) - gammaln(z + 1)))
+    if model == "logistic":
+        return dict(hess=lambda y, z: np.exp(y) / (1 + np.exp(y)) ** 2, score=lambda y, z: z - np.exp(y) / (1 + np.exp(y)),
+                    llh=lambda y, z: np.sum(z * y - np.log(1 + np.exp(y))))
+    if model == "gamma":
+        return dict(hess=lambda y, z: a * z * np.exp(-y), score=lambda y, z: a * (z * np.exp(-y) - 1),
+                    llh=lambda y, z: np.sum(-a * z * np.exp(-y) + (a - 1) * np.log(z) - a * y + a * np.log(a) - gammaln(a)))
+    if model == "gaussian":
+        return dict(hess=lambda y, z: np.full(len(y), 1 / sg ** 2), score=lambda y, z: (z - y) / sg ** 2,
+                    llh=lambda y, z: np.sum(-.5 * (z - y) ** 2 / sg ** 2) - len(y) * (np.log(sg) + np.log(2 * np.pi) / 2))
+    raise ValueError(model)
+
+
+def calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel="matern", likparms=None, max_iter=50,
+                           convg=1e-6, prior_mean=None):
+    """R/vecchia_laplace_NR.R:31-155 (no missing data)."""
+    z = np.asarray(z, dtype=np.float64)
+    fam = vl_family(likelihood_model, likparms)
+    pm = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, float)
+    y_o = pm.copy()                                                    # :81-82
+    convgd, tot = False, 0
+    for i in range(1, max_iter + 1):                                   # :88
+        y_prev = y_o
+        D = 1 / fam["hess"](y_o, z)                                    # :93,100
+        u = fam["score"](y_o, z)                                       # :101
+        pseudo = D * u + y_o - pm                                      # :105
+        mu = vecchia_prediction_mean(pseudo, va, covparms, D, covmodel)    # :112-113
+        y_o = mu + pm                                                  # :115
+        if np.max(np.abs(y_o - y_prev)) < convg:                       # :124
+            convgd, tot = True, i
+            break
+        tot += 1
+    return dict(mean=mu + pm, cnvgd=convgd, iter=tot, t=pseudo + pm, D=D, model_llh=fam["llh"], prior_mean=pm)
+
+
+def vecchia_laplace_likelihood(z, va, likelihood_model, covparms, likparms=None, covmodel="matern", max_iter=50,
+                               convg=1e-5, prior_mean=None):
+    """R/vecchia_laplace_NR.R:361-416."""
+    z = np.asarray(z, dtype=np.float64)
+    post = calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, prior_mean)
+    if not post["cnvgd"]:
+        return -np.inf                                                 # :373
+    pm = post["prior_mean"]
+    z_pseudo = post["t"] - pm                                          # :381
+    D = post["D"]
+    marg = vecchia_likelihood(z_pseudo, va, covparms, D, covmodel)     # :396-397
+    true_llh = post["model_llh"](post["mean"], z)                      # :402
+    cond = np.sum(-0.5 * np.log(2 * np.pi * D) - 0.5 * (z_pseudo - (post["mean"] - pm)) ** 2 / D)   # :405
+    return marg - cond + true_llh                                      # :408-409

@@ -317,6 +317,65 @@ def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
     assert abs(ll2 - G.vecchia_likelihood_U(z, U_obj)) <= 1e-9 * abs(ll2)
 
 
+@pytest.mark.parametrize("cond", ["SGV", "z"])
+def test_posterior_mean_on_device(cond):
+    # vecchia_prediction(..., 'meanmat'): createU + U2V + vecchia_mean (R/vecchia_prediction.R:17-56,118-142)
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(8)
+    n, m = 900, 15
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    cp = [1.1, 0.2, 1.5]
+    tau = 0.05 + 0.3 * rng.random(n)
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+    ref = R.vecchia_prediction_mean(z, vb, cp, tau)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+    out = G.vecchia_prediction(z, va, cp, tau)["mu_obs"]
+    assert va[("_plan", 0)].has_posterior
+    np.testing.assert_allclose(out, ref, rtol=0, atol=1e-8 * np.abs(ref).max())
+    if cond == "z":
+        return        # cond.yz='z' keeps only the marginal of z exact, not the joint of (y, z): no kriging identity
+    # m = n-1: the exact kriging mean  K (K + diag(tau))^{-1} z
+    n2 = 60
+    l2 = rng.random((n2, 2)); z2 = rng.standard_normal(n2); t2 = 0.1 + rng.random(n2)
+    va2 = G.vecchia_specify(l2, n2 - 1, ordering="maxmin", cond_yz=cond)
+    K = R.MaternFun(R.rdist(l2), cp)
+    exact = K @ np.linalg.solve(K + np.diag(t2), z2)
+    np.testing.assert_allclose(G.vecchia_prediction(z2, va2, cp, t2)["mu_obs"], exact, rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("model", ["poisson", "logistic", "gamma", "gaussian"])
+def test_vecchia_laplace_likelihood(model):
+    # BASELINE config 5 path: Newton-Raphson of R/vecchia_laplace_NR.R:88-130, one U_NZentries call with vector
+    # pseudo-nuggets per step, then vecchia_laplace_likelihood (:361-416)
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(21)
+    n, m = 500, 10
+    locs = rng.random((n, 2))
+    cp = [0.6, 0.15, 1.5]
+    y = np.linalg.cholesky(R.MaternFun(R.rdist(locs), cp) + 1e-10 * np.eye(n)) @ rng.standard_normal(n)
+    if model == "poisson":
+        z = rng.poisson(np.exp(y)).astype(float)
+    elif model == "logistic":
+        z = (rng.random(n) < 1 / (1 + np.exp(-y))).astype(float)
+    elif model == "gamma":
+        z = rng.gamma(2.0, np.exp(y) / 2.0)
+    else:
+        z = y + np.sqrt(.1) * rng.standard_normal(n)
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    post_ref = R.calculate_posterior_VL(z, vb, model, cp)
+    ll_ref = R.vecchia_laplace_likelihood(z, vb, model, cp)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    post = G.calculate_posterior_VL(z, va, model, cp)
+    assert post["cnvgd"] and post_ref["cnvgd"] and post["iter"] == post_ref["iter"]
+    np.testing.assert_allclose(post["mean"], post_ref["mean"], rtol=0, atol=1e-7)
+    ll = G.vecchia_laplace_likelihood(z, va, model, cp)
+    assert abs(ll - ll_ref) <= 1e-7 * abs(ll_ref)
+    with pytest.raises(ValueError):
+        G.calculate_posterior_VL(np.full(n, -1.0), va, "poisson", cp)      # data outside the support (:52-54)
+
+
 def test_m_equals_n_minus_1_exact_density():
     # vignette identity on the GPU path: m = n-1 => exact multivariate normal log density
     G = _need_gpu()
