@@ -50,7 +50,7 @@ def build_workload(n, m, d, rank, world, seed=0, sgv=False):
     z = np.random.default_rng(seed + 1).standard_normal(n)
     a = (rank * n) // world
     b = ((rank + 1) * n) // world
-    NN = S.find_ordered_nn(locs, m, rows=(a, b))          # only this rank's rows are searched
+    NN = S.find_ordered_nn_gpu(locs, m, rows=(a, b), device=int(os.environ.get("LOCAL_RANK", "0")))   # this rank's rows only
     revNN = NN[:, ::-1].copy()
     if sgv:
         revCond = S.whichCondOnLatent(NN)[:, ::-1].copy()   # cond.yz='SGV' (R/vecchia_specify.R:182-183)

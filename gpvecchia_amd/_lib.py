@@ -30,7 +30,7 @@ EXPORTS = [
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
     "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
-    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean",
+    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
     L.gpv_plan_posterior_levels.argtypes = [vp, ip]
     L.gpv_plan_get_posterior_mean.argtypes = [vp, dp]
     L.gpv_loglik_from_sums.argtypes = [dp, i64, dp]
+    L.gpv_find_ordered_nn.argtypes = [C.c_int, dp, i64, C.c_int, C.c_int, i64, i64, ip]
     L.gpv_whichCondOnLatent.argtypes = [ip, i64, C.c_int, i64, ip]
     _lib = L
     return L

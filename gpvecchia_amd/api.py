@@ -206,7 +206,7 @@ def EsqeFun(distmat, covparms):
 # vecchia_specify — R/vecchia_specify.R:29-240
 # ---------------------------------------------------------------------------
 def vecchia_specify(locs, m=-1, ordering=None, cond_yz=None, locs_pred=None, ordering_pred=None, pred_cond=None,
-                    conditioning=None, mra_options=None, ic0=False, verbose=False, NNarray=None):
+                    conditioning=None, mra_options=None, ic0=False, verbose=False, NNarray=None, nn_backend="auto"):
     """Parameter-independent specification of the Vecchia approximation.
 
     Implemented: no prediction locations, conditioning='NN', ordering in
@@ -254,8 +254,11 @@ def vecchia_specify(locs, m=-1, ordering=None, cond_yz=None, locs_pred=None, ord
         raise ValueError(f"ordering='{ordering}' not defined")
     locsord = locs[ord_ - 1]
     obs = np.ones(n, dtype=bool)
-    if NNarray is None:
-        NNarray = S.find_ordered_nn(locsord, m)                              # :157-159
+    if NNarray is None:                                                      # :157-159
+        # both searches implement the same exact definition and return identical arrays (tests); "gpu" is the
+        # library's brute-force kernel, "host" the cKDTree search
+        use_gpu = nn_backend == "gpu" or (nn_backend == "auto" and L.device_count() > 0 and n >= 2000)
+        NNarray = S.find_ordered_nn_gpu(locsord, m) if use_gpu else S.find_ordered_nn(locsord, m)
     NNarray = np.asarray(NNarray).astype(np.int32)
     if cond_yz == "SGV":                                                     # :182-183
         Cond = S.whichCondOnLatent(NNarray, firstind_pred=n + 1)

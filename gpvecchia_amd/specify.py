@@ -134,6 +134,18 @@ def find_ordered_nn(locs, m, workers=-1, rows=None):
     return NN
 
 
+def find_ordered_nn_gpu(locs, m, rows=None, device=0):
+    """Same result as find_ordered_nn (bit-exact), computed by the library's brute-force GPU kernel
+    (gpv_find_ordered_nn).  Returns int32 (n, m+1), 1-based, 0 = NA; rows outside `rows` stay 0."""
+    from . import _lib as L
+    locs = np.asfortranarray(locs, dtype=np.float64)
+    n, d = locs.shape
+    a, b = (0, n) if rows is None else (int(rows[0]), int(rows[1]))
+    out = np.zeros((n, m + 1), dtype=np.int32, order="F")
+    L.check(L.lib().gpv_find_ordered_nn(int(device), L.dptr(locs), n, d, int(m), a, b, L.iptr(out)), "gpv_find_ordered_nn")
+    return np.ascontiguousarray(out)
+
+
 def whichCondOnLatent(NNarray, firstind_pred=None, native=True):
     """R/whichCondOnLatent.R:2-26 (SGV rule).  NNarray int (n, m+1), 1-based, 0 = NA.
     Returns int8 (n, m+1): 1 TRUE (latent), 0 FALSE (observed), -1 NA.

@@ -181,6 +181,13 @@ int gpv_numerator_from_sums(const double *sums, double *logdet_num, double *quad
  * Cond out: n x ncolNN column-major R logical (1/0/NA_INTEGER). */
 int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t firstind_pred, int *Cond);
 
+/* Exact ordered nearest neighbours on the GPU (brute force, bit-exact): the definition of R/NN_kdtree.R:73-83
+ * (what GpGp::find_ordered_nn computes at R/vecchia_specify.R:159, without its random jitter).  locs: n x dim
+ * column-major in the ORDERED layout; NNarray: n x (m+1) column-major, 1-based, 0 = NA; only rows
+ * [row_begin, row_end) are written (a row shard of a multi-GPU plan). */
+int gpv_find_ordered_nn(int device, const double *locs, int64_t n, int dim, int m, int64_t row_begin, int64_t row_end,
+                        int *NNarray);
+
 #ifdef __cplusplus
 }
 #endif

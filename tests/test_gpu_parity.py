@@ -376,6 +376,33 @@ def test_vecchia_laplace_likelihood(model):
         G.calculate_posterior_VL(np.full(n, -1.0), va, "poisson", cp)      # data outside the support (:52-54)
 
 
+@pytest.mark.parametrize("n,m,d", [(700, 10, 2), (3000, 30, 2), (1500, 7, 1), (1200, 20, 3), (900, 12, 5), (40, 60, 2)])
+def test_gpu_ordered_nn_bit_exact(n, m, d):
+    # north-star: neighbour index arrays bit-exact.  GPU brute force vs the oracle's literal findOrderedNN
+    # (R/NN_kdtree.R:73-83) and vs the host (cKDTree) search of the mirror.
+    G = _need_gpu()
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    rng = np.random.default_rng(n + d)
+    locs = rng.random((n, d))
+    a = S.find_ordered_nn_gpu(locs, m)
+    assert np.array_equal(a, S.find_ordered_nn(locs, m))
+    if n <= 1500:
+        assert np.array_equal(a, np.nan_to_num(R.findOrderedNN(locs, m)).astype(np.int32))
+    sh = S.find_ordered_nn_gpu(locs, m, rows=(n // 3, n // 2))
+    assert np.array_equal(sh[n // 3: n // 2], a[n // 3: n // 2]) and not sh[: n // 3].any() and not sh[n // 2:].any()
+
+
+def test_gpu_ordered_nn_ties_and_duplicates():
+    G = _need_gpu()
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    g = np.stack(np.meshgrid(np.arange(25.0), np.arange(17.0)), -1).reshape(-1, 2)      # regular grid: exact ties everywhere
+    g = np.vstack([g, g[:9]])                                                         # exact duplicates
+    a = S.find_ordered_nn_gpu(g, 12)
+    assert np.array_equal(a, np.nan_to_num(R.findOrderedNN(g, 12)).astype(np.int32))   # lower index wins, like order()
+
+
 def test_m_equals_n_minus_1_exact_density():
     # vignette identity on the GPU path: m = n-1 => exact multivariate normal log density
     G = _need_gpu()
