@@ -8,4 +8,6 @@ from .api import (EsqeFun, MaternFun, Plan, U2V, U_NZentries, U_NZentries_mat, c
 
 from .laplace import calculate_posterior_VL, vecchia_laplace_likelihood, vecchia_prediction  # noqa: F401,E402
 
+from .wrappers import vecchia_estimate  # noqa: F401,E402
+
 __version__ = "0.1.0"
