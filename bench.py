@@ -121,7 +121,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the collective path runs even at N = 1
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import gpvecchia_amd as G
@@ -153,14 +154,14 @@ def main():
 
     def step():
         plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
-        if world > 1:
+        if use_dist:
             dist.all_reduce(sums, op=dist.ReduceOp.SUM)       # the ONE collective: 64 bytes over xGMI
         host = sums.cpu().numpy()                             # scalar on the host (implicit stream sync)
         return G.loglik_from_sums(host, n) if args.mode == "S" else G.loglik_z_from_sums(host, n)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -175,7 +176,7 @@ def main():
         kernel_ms.append(plan.last_kernel_ms())               # hipEvent pair on the launch stream, already complete
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -224,7 +225,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (lo, b))
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

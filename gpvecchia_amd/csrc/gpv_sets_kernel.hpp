@@ -43,6 +43,9 @@
 #ifndef GPV_MINW_LARGE
 #define GPV_MINW_LARGE 2      // for P > 32 (=> <= 256 VGPRs)
 #endif
+#ifndef GPV_COV_UNROLL
+#define GPV_COV_UNROLL 2       // unroll factor of the covariance rounds
+#endif
 #ifndef GPV_CHUNK
 #define GPV_CHUNK 8           // pivot-row values fetched per LDS burst in the sweep
 #endif
@@ -114,13 +117,14 @@ __device__ __forceinline__ void wave_sync()
 // 1/x for a pivot: v_rcp_f64 seed (~2^-23) + two Newton steps, branch free so the whole
 // elimination sweep stays one basic block.  The exponent is clamped with one integer op
 // (pivots above ~2^990, e.g. an Inf nugget, behave like 1/Inf = 0: their multipliers vanish
-// below rounding); non-positive / NaN pivots are caught by the failure test, not here.
+// below rounding).  The result is > 0 exactly when the pivot is: 0 -> NaN, negative -> negative, NaN -> NaN,
+// which is what the failure test reads.
 __device__ __forceinline__ double rcp_pivot(double x)
 {
     unsigned long long u = __double_as_longlong(x);
-    unsigned hi = (unsigned)(u >> 32);
-    hi = hi < 0x7DE00000u ? hi : 0x7DE00000u;
-    x = __longlong_as_double(((unsigned long long)hi << 32) | (u & 0xffffffffull));
+    int hi = (int)(u >> 32);
+    hi = hi < 0x7DE00000 ? hi : 0x7DE00000;          // signed: negative pivots keep their sign (and fail the > 0 test)
+    x = __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (u & 0xffffffffull));
     double r = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r, 1.0);
     r = __builtin_fma(r, e, r);
@@ -321,7 +325,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
-#pragma unroll 2
+#pragma unroll GPV_COV_UNROLL
                 for (int s = 1; s <= H; ++s) {
                     const unsigned tj = (unsigned)(row[q] + s);
                     int j = (int)(tj < tj - P ? tj : tj - P);            // (row + s) mod P via unsigned min
@@ -402,9 +406,9 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         wave_sync();
 
         // ---- Gauss-Jordan sweep over pivots 0..P-2 ------------------------------------
-        double pown[RPL], prinv[RPL];                  // each row's own pivot and its reciprocal (kept out of a[] indexing)
+        double prinv[RPL];                             // reciprocal of each row's own pivot (kept out of a[] indexing)
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) { pown[q] = 1.0; prinv[q] = 1.0; }
+        for (int q = 0; q < RPL; ++q) prinv[q] = 1.0;
 #pragma unroll
         for (int j = 0; j < P - 1; ++j) {
             double *cb = L.col[j & 1][sub];
@@ -423,7 +427,6 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 const bool isp = (row[q] == j);
-                pown[q] = isp ? pj : pown[q];
                 prinv[q] = isp ? rinv : prinv[q];
                 const double aj = isp ? 0.0 : a[q][j];   // the pivot row itself is left untouched
                 w[q] = aj * rinv;
@@ -452,9 +455,10 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         bool bad = false;
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
-            pown[q] = (row[q] == P - 1) ? vlast : pown[q];
-            // LAPACK dpotrf: a pivot <= 0 or NaN -> not positive definite (src/U_NZentries.cpp:60-66)
-            bad = bad | (lane_on && row[q] < P && !(pown[q] > 0.0));
+            // LAPACK dpotrf: a pivot <= 0 or NaN -> not positive definite (src/U_NZentries.cpp:60-66); the sign / NaN-ness
+            // of a pivot survives in its reciprocal, the last pivot is tested directly
+            const bool okp = (row[q] == P - 1) ? (vlast > 0.0) : (prinv[q] > 0.0);
+            bad = bad | (lane_on && row[q] < P && !okp);
         }
         const bool fail = (__ballot(bad) & setmask) != 0ull;
         const double rs = rsqrt_pos(vlast);            // M[n0-1] = d_k = 1/R[n0-1][n0-1]
