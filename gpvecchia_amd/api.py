@@ -331,9 +331,27 @@ def createU(vecchia_approx, covparms, nuggets, covmodel="matern", device=0):
     keep = np.arange(revNN.shape[1])[None, :] < n0[:, None]
     vals = np.concatenate([np.ascontiguousarray(Lent)[keep], Zent])
     U = sp.csc_matrix((vals, (prep["colindices"] - 1, prep["rowpointers"] - 1)), shape=(size, size))   # :161-162
-    if np.any(nug == 0):
-        raise NotImplementedError("zero-nugget surgery of R/createU.R:173-193 is not built yet")
-    return dict(U=U, latent=latent, ord=va["ord"], obs=va["obs"], zero_nugg={}, ord_pred=va["ord_pred"],
+    ord_, obs, zero_nugg = va["ord"], va["obs"], {}
+    if np.any(nug == 0):                                                     # :173-193
+        # rows/columns of observations with zero noise are removed; the latent variable they pin down
+        # takes their place as an "observed" row
+        Ucsc = U.tocsc()
+        diag = Ucsc.diagonal()
+        inds_U = np.where(np.isinf(diag))[0]                                 # :178
+        cond_on = np.array([Ucsc.indices[Ucsc.indptr[j]:Ucsc.indptr[j + 1]].min() for j in inds_U])   # :179
+        keep = np.ones(size, dtype=bool)
+        keep[inds_U] = False
+        U = Ucsc[keep][:, keep].tocsc()                                      # :180
+        inds_z = np.where(np.isin(np.where(~latent)[0], inds_U))[0]          # :183 (0-based positions)
+        inds_locs = np.where(np.isin(np.where(latent)[0], cond_on))[0]       # :184
+        zero_nugg = dict(inds_U=inds_U + 1, inds_z=inds_z + 1, inds_locs=inds_locs + 1)
+        latent = latent.copy()
+        latent[cond_on] = False                                              # :188
+        latent = latent[keep]                                                # :189
+        rest = np.setdiff1d(np.arange(len(ord_)), inds_locs)
+        ord_ = np.concatenate([ord_[rest], ord_[inds_locs]])                 # :190
+        obs = np.concatenate([obs[rest], obs[inds_locs]])                    # :191
+    return dict(U=U, latent=latent, ord=ord_, obs=obs, zero_nugg=zero_nugg, ord_pred=va["ord_pred"],
                 ord_z=va["ord_z"], cond_yz=va["cond_yz"], ic0=va["ic0"], Lentries=Lent, Zentries=Zent)
 
 

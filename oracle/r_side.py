@@ -407,8 +407,24 @@ def createU(va, covparms, nuggets, covmodel="matern"):
     U = np.zeros((size, size))
     # :161-162 sparseMatrix(i=colindices, j=rowpointers, x=...) (duplicates would be summed)
     np.add.at(U, (prep["colindices"] - 1, prep["rowpointers"] - 1), vals)
-    return dict(U=U, latent=latent, ord=ord_, obs=va["obs"], ord_z=va["ord_z"], ord_pred=va["ord_pred"],
-                cond_yz=va["cond_yz"], ic0=va["ic0"], U_entries=ent,
+    obs = va["obs"]
+    zero_nugg = {}
+    if np.any(nug == 0):                                            # :173-193, literal
+        inds_U = np.where(np.isinf(np.diag(U)))[0]                  # :178
+        cond_on = np.array([np.where(U[:, j] != 0)[0].min() for j in inds_U])     # :179
+        keep = np.ones(size, dtype=bool)
+        keep[inds_U] = False
+        U = U[np.ix_(keep, keep)]                                   # :180
+        inds_locs = np.where(np.isin(np.where(latent)[0], cond_on))[0]            # :184
+        zero_nugg = dict(inds_U=inds_U + 1, inds_locs=inds_locs + 1)
+        latent = latent.copy()
+        latent[cond_on] = False                                     # :188
+        latent = latent[keep]                                       # :189
+        rest = np.setdiff1d(np.arange(len(ord_)), inds_locs)
+        ord_ = np.concatenate([ord_[rest], ord_[inds_locs]])        # :190
+        obs = np.concatenate([obs[rest], obs[inds_locs]])           # :191
+    return dict(U=U, latent=latent, ord=ord_, obs=obs, ord_z=va["ord_z"], ord_pred=va["ord_pred"],
+                cond_yz=va["cond_yz"], ic0=va["ic0"], U_entries=ent, zero_nugg=zero_nugg,
                 triplets=(prep["colindices"].copy(), prep["rowpointers"].copy(), vals))
 
 

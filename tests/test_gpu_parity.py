@@ -426,6 +426,26 @@ def test_vecchia_estimate_driver():
     assert -est["neg_loglik"] > R.vecchia_likelihood(est["z"], vb, [.9 * var_res, 0.13, .8], .1 * var_res) - 1e-6
 
 
+def test_zero_nuggets_surgery():
+    # R/createU.R:83-86,173-193 through the GPU U_NZentries + host assembly
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(14)
+    n, m = 400, 9
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    cp = [1.0, 0.3, 0.5]
+    tau = np.where(rng.random(n) < 0.25, 0.0, 0.15)
+    for cond in ("SGV", "z"):
+        vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+        ref = R.createU(vb, cp, tau)
+        va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+        out = G.createU(va, cp, tau)
+        assert np.array_equal(out["latent"], ref["latent"]) and np.array_equal(out["ord"], ref["ord"])
+        np.testing.assert_allclose(out["U"].toarray(), ref["U"], rtol=0, atol=1e-9 * np.abs(ref["U"]).max())
+        ll_ref = R.vecchia_likelihood_U(z, ref)
+        assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_ref) <= 1e-8 * abs(ll_ref)
+
+
 def test_m_equals_n_minus_1_exact_density():
     # vignette identity on the GPU path: m = n-1 => exact multivariate normal log density
     G = _need_gpu()

@@ -197,6 +197,26 @@ def test_failure_and_edge_semantics():
         R.U_NZentries(1, 3, locs2, revNN, revCond, nug, nug, "gauss", [1, .5, 1.5])
 
 
+def test_zero_nuggets_interpolation_identity():
+    # R/createU.R:83-86,173-193: observations without noise.  With m = n-1 the likelihood must equal the exact
+    # density of z ~ N(0, K + diag(tau)) with tau_i = 0 on part of the data.
+    from scipy.stats import multivariate_normal
+    rng = np.random.default_rng(4)
+    n = 30
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    cp = [1.0, 0.3, 0.5]
+    tau = np.where(rng.random(n) < 0.3, 0.0, 0.2)
+    assert (tau == 0).sum() > 3
+    K = R.MaternFun(R.rdist(locs), cp)
+    exact = multivariate_normal.logpdf(z, np.zeros(n), K + np.diag(tau))
+    for cond in ("SGV", "y"):
+        va = R.vecchia_specify(locs, n - 1, ordering="maxmin", cond_yz=cond)
+        Uo = R.createU(va, cp, tau)
+        assert Uo["U"].shape[0] == 2 * n - (tau == 0).sum() and np.isfinite(Uo["U"]).all()
+        assert (~Uo["latent"]).sum() == n
+        assert abs(R.vecchia_likelihood_U(z, Uo) - exact) < 1e-9 * abs(exact)
+
+
 def test_U_NZentries_mat_matches_kernel_path_without_nugget():
     locs, va = _random_case(50, 6, 2, 2, cond="y")
     cp = [1.0, 0.3, 0.5]
