@@ -108,6 +108,46 @@ class Plan:
         return float(ms.value)
 
 
+class MultiPlan:
+    """gpv_mplan: the same vecchia.approx spread over several GPUs of one host process (row shards)."""
+
+    def __init__(self, locsord, revNNarray, revCond, devices):
+        locs = np.asfortranarray(locsord, dtype=np.float64)
+        self.Nlocs, self.dim = locs.shape
+        nn = L.as_r_int_matrix(revNNarray)
+        cd = _cond_to_r(revCond)
+        self.p = nn.shape[1]
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self._h = C.c_void_p()
+        L.check(L.lib().gpv_mplan_create(C.byref(self._h), L.iptr(dev), int(dev.size), self.Nlocs, self.dim, self.p,
+                                         L.dptr(locs), L.iptr(nn), L.iptr(cd)), "gpv_mplan_create")
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                L.lib().gpv_mplan_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def set_data(self, z_ord):
+        z = np.ascontiguousarray(z_ord, dtype=np.float64)
+        L.check(L.lib().gpv_mplan_set_data(self._h, L.dptr(z)), "gpv_mplan_set_data")
+
+    def eval(self, covmodel, covparms, nuggets, flags):
+        cp = np.ascontiguousarray(covparms, dtype=np.float64)
+        ng = np.ascontiguousarray(np.atleast_1d(nuggets), dtype=np.float64)
+        s = np.zeros(NSUMS)
+        L.check(L.lib().gpv_mplan_eval(self._h, str(covmodel).encode(), L.dptr(cp), int(cp.size), L.dptr(ng),
+                                       int(ng.size), int(flags), L.dptr(s)), "gpv_mplan_eval")
+        return s
+
+    def Lentries(self):
+        out = np.zeros((self.Nlocs, self.p), dtype=np.float64, order="F")
+        L.check(L.lib().gpv_mplan_get_Lentries(self._h, L.dptr(out)), "gpv_mplan_get_Lentries")
+        return out
+
+
 def _cond_to_r(revCond):
     """logical matrix -> R's int representation: NaN (float input) or -1 (int8 input) -> NA_INTEGER."""
     rc = np.asarray(revCond)

@@ -826,6 +826,93 @@ void gpv_EsqeFun(const double *distmat, const int *nelem, const double *covparms
 }
 
 // ---------------------------------------------------------------------------------------
+// several GPUs from ONE host process (what an R session would use): one plan per device, contiguous row shards,
+// replicated locations / data, the 8-double partial sums added on the host in device order (deterministic).
+// The one-process-per-GPU route (torchrun + RCCL all-reduce) uses gpv_plan_* directly, see bench.py.
+// ---------------------------------------------------------------------------------------
+struct gpv_mplan {
+    std::vector<gpv_plan *> plans;
+    int64_t Nlocs = 0;
+    int p = 0;
+};
+
+int gpv_mplan_create(gpv_mplan **out, const int *devices, int ndev, int64_t Nlocs, int dim, int ncolNN,
+                     const double *locs, const int *revNN, const int *revCond)
+{
+    if (!out || !devices || ndev < 1) return GPV_ERR_BAD_ARG;
+    *out = nullptr;
+    gpv_mplan *mp = new gpv_mplan();
+    mp->Nlocs = Nlocs;
+    mp->p = ncolNN;
+    for (int g = 0; g < ndev; ++g) {
+        gpv_plan *pl = nullptr;
+        const int64_t a = (Nlocs * g) / ndev, b = (Nlocs * (g + 1)) / ndev;     // rows beyond the first m cost the same
+        const int rc = gpv_plan_create(&pl, devices[g], Nlocs, dim, ncolNN, locs, revNN, revCond, a, b);
+        if (rc != GPV_OK) {
+            for (gpv_plan *q : mp->plans) gpv_plan_destroy(q);
+            delete mp;
+            return rc;
+        }
+        mp->plans.push_back(pl);
+    }
+    *out = mp;
+    return GPV_OK;
+}
+
+int gpv_mplan_destroy(gpv_mplan *mp)
+{
+    if (!mp) return GPV_OK;
+    for (gpv_plan *q : mp->plans) gpv_plan_destroy(q);
+    delete mp;
+    return GPV_OK;
+}
+
+int gpv_mplan_set_data(gpv_mplan *mp, const double *z_ord)
+{
+    if (!mp) return GPV_ERR_BAD_ARG;
+    for (gpv_plan *q : mp->plans) {
+        const int rc = gpv_plan_set_data(q, z_ord);
+        if (rc != GPV_OK) return rc;
+    }
+    return GPV_OK;
+}
+
+int gpv_mplan_eval(gpv_mplan *mp, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
+                   int64_t n_nuggets, int flags, double *sums)
+{
+    if (!mp || !sums) return GPV_ERR_BAD_ARG;
+    if (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN)) return GPV_ERR_BAD_ARG;       // the posterior pass does not shard
+    for (gpv_plan *q : mp->plans) {                                              // all devices start before any is awaited
+        const int rc = gpv_plan_eval(q, covType, covparms, ncovparms, nuggets, n_nuggets, flags, nullptr, nullptr);
+        if (rc != GPV_OK) return rc;
+    }
+    for (int s = 0; s < GPV_NSUMS; ++s) sums[s] = 0.0;
+    for (gpv_plan *q : mp->plans) {
+        double part[GPV_NSUMS];
+        const int rc = gpv_plan_get_sums(q, part);
+        if (rc != GPV_OK) return rc;
+        for (int s = 0; s < GPV_NSUMS; ++s) sums[s] += part[s];
+    }
+    return GPV_OK;
+}
+
+int gpv_mplan_get_Lentries(gpv_mplan *mp, double *Lentries)
+{
+    // column-major Nlocs x ncolNN: every device's shard lands in its rows
+    if (!mp || !Lentries) return GPV_ERR_BAD_ARG;
+    for (gpv_plan *q : mp->plans) {
+        const int64_t rows = q->rows;
+        if (rows == 0) continue;
+        std::vector<double> tmp((size_t)rows * mp->p);
+        const int rc = gpv_plan_get_Lentries(q, tmp.data());
+        if (rc != GPV_OK) return rc;
+        for (int c = 0; c < mp->p; ++c)
+            std::memcpy(Lentries + (size_t)c * mp->Nlocs + q->row_begin, tmp.data() + (size_t)c * rows, sizeof(double) * (size_t)rows);
+    }
+    return GPV_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // host-side setup helper (parameter-independent, runs once per data set; "next" row §8f-3)
 // ---------------------------------------------------------------------------------------
 int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t firstind_pred, int *Cond)

@@ -174,6 +174,20 @@ int gpv_loglik_from_sums(const double *sums, int64_t n, double *loglik);
 int gpv_numerator_from_sums(const double *sums, double *logdet_num, double *quadform_num);
 
 /* -------------------------------------------------------------------------
+ * Several GPUs from ONE host process (an R session has one): one plan per listed device, contiguous row shards,
+ * replicated locations / data; gpv_mplan_eval starts every device, then adds the GPV_NSUMS partial sums on the host
+ * in device order (64 bytes per device; deterministic).  Flags: GPV_WANT_U | GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR
+ * (the posterior pass does not shard).  `devices` may name a device more than once (then its shards share it). */
+typedef struct gpv_mplan gpv_mplan;
+int gpv_mplan_create(gpv_mplan **mplan, const int *devices, int ndev, int64_t Nlocs, int dim, int ncolNN,
+                     const double *locs, const int *revNNarray, const int *revCondOnLatent);
+int gpv_mplan_destroy(gpv_mplan *mplan);
+int gpv_mplan_set_data(gpv_mplan *mplan, const double *z_ord);
+int gpv_mplan_eval(gpv_mplan *mplan, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
+                   int64_t n_nuggets, int flags, double *sums /* GPV_NSUMS, host */);
+int gpv_mplan_get_Lentries(gpv_mplan *mplan, double *Lentries /* Nlocs x ncolNN col-major */);
+
+/* -------------------------------------------------------------------------
  * Host-side setup helper (no GPU needed, parameter independent, once per data set).
  * Not part of the reference's FFI: the reference runs this as interpreted R
  * (R/whichCondOnLatent.R:2-26, O(n m^3)); exported so that SGV plans can be built at n = 1e6.

@@ -195,6 +195,31 @@ def test_sharded_plans_add_up():
     assert abs(G.loglik_z_from_sums(tot, n) - ll_ref) <= LL_RTOL * abs(ll_ref)
 
 
+def test_multiplan_single_process_shards():
+    # gpv_mplan_*: several shards driven from one host process (here all on device 0: the box has one GPU)
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, m = 3001, 20
+    locs, z, va = _case(n, m, 2, 77, "z")
+    cp, tau = [1.0, 0.1, 1.5], 0.1
+    pva = _to_product_va(va)
+    prep = pva["U_prep"]
+    one = G.Plan(pva["locsord"], prep["revNNarray"], prep["revCond"])
+    one.set_data(z)
+    one.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
+    mp = G.MultiPlan(pva["locsord"], prep["revNNarray"], prep["revCond"], devices=[0, 0, 0])
+    mp.set_data(z)
+    s = mp.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
+    np.testing.assert_allclose(s, one.sums(), rtol=1e-12)
+    np.testing.assert_array_equal(mp.Lentries(), one.Lentries())
+    ll_ref = R.vecchia_likelihood(z, va, cp, tau)
+    assert abs(G.loglik_z_from_sums(s, n) - ll_ref) <= LL_RTOL * abs(ll_ref)
+    with pytest.raises(G.GpvError):
+        mp.eval("matern", cp, tau, G.GPV_WANT_DENOM)            # the posterior pass does not shard
+    with pytest.raises(G.GpvError):
+        G.MultiPlan(pva["locsord"], prep["revNNarray"], prep["revCond"], devices=[0, 7])   # no such device here
+
+
 def test_failed_rows_and_errors():
     G = _need_gpu()
     from oracle import r_side as R
