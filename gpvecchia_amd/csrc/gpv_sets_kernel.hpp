@@ -122,9 +122,10 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ double rcp_pivot(double x)
 {
     unsigned long long u = __double_as_longlong(x);
-    int hi = (int)(u >> 32);
-    hi = hi < 0x7DE00000 ? hi : 0x7DE00000;          // signed: negative pivots keep their sign (and fail the > 0 test)
-    x = __longlong_as_double(((unsigned long long)(unsigned)hi << 32) | (u & 0xffffffffull));
+    unsigned hi = (unsigned)(u >> 32);
+    // clamp only [2^991, +Inf]: negative pivots keep their sign and NaNs stay NaN (both must fail the > 0 test)
+    hi = (hi - 0x7DE00001u <= 0x7FF00000u - 0x7DE00001u) ? 0x7DE00000u : hi;
+    x = __longlong_as_double(((unsigned long long)hi << 32) | (u & 0xffffffffull));
     double r = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r, 1.0);
     r = __builtin_fma(r, e, r);

@@ -242,6 +242,19 @@ def test_failed_rows_and_errors():
     with pytest.raises(G.GpvError) as e:
         G.U_NZentries(1, 4, locs, bad, revCond, nug, nug, "matern", [1, .5, 1.5])
     assert e.value.status == 8
+    # NaN coordinate / NaN nugget -> NaN block -> every row that touches it fails (chol throws in the reference)
+    lnan = locs.copy(); lnan[3, 0] = np.nan
+    ref = R.U_NZentries(1, 4, lnan, revNN, revCond, nug, nug, "matern", [1, .5, 1.5])
+    out = G.U_NZentries(1, 4, lnan, revNN, revCond, nug, nug, "matern", [1, .5, 1.5])
+    assert out["n_failed"] == ref["n_failed"] == 3 and np.all(out["Lentries"][3] == 0)
+    nnan = nug.copy(); nnan[0] = np.nan
+    rc2 = revCond.copy(); rc2[3] = [0, 0, 1]
+    locs3 = np.array([[0.0, 0.0], [0.3, 0.1], [1.0, 1.0], [0.5, 0.2]])
+    rv2 = np.array([[0, 0, 1], [0, 0, 2], [1, 2, 3], [1, 3, 4]], float)
+    rc3 = np.array([[np.nan, np.nan, 1], [np.nan, np.nan, 1], [0, 1, 1], [0, 0, 1]], float)
+    ref = R.U_NZentries(1, 4, locs3, rv2, rc3, nnan, nnan, "matern", [1, .5, 1.5])
+    out = G.U_NZentries(1, 4, locs3, rv2, rc3, nnan, nnan, "matern", [1, .5, 1.5])
+    assert out["n_failed"] == ref["n_failed"] and np.array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
     # zero nugget -> Zentries -/+Inf like the reference; huge nugget (removeNAs) -> ~0 weight
     out = G.U_NZentries(1, 4, locs, revNN, revCond, np.zeros(4), np.zeros(4), "matern", [1, .5, 1.5])
     assert np.isinf(out["Zentries"]).all()
