@@ -484,6 +484,84 @@ def test_zero_nuggets_surgery():
         assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_ref) <= 1e-8 * abs(ll_ref)
 
 
+def test_full_size_properties_n1e6_m30():
+    """BASELINE.json's full size (n = 1e6, m = 30, 2-D, Matern 1.5): size-independent properties.
+      * neighbour arrays: a random sample of rows equals the brute-force definition bit for bit;
+      * U entries: a random sample of conditioning sets equals the oracle (sub-problem with remapped indices);
+      * the fused likelihood sums equal the same sums recomputed on the host from the U entries left in HBM;
+      * additivity: shard sums add up to the unsharded sums; evaluation is bitwise reproducible."""
+    G = _need_gpu()
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    n, m, p = 1_000_000, 30, 31
+    rng = np.random.default_rng(0)
+    locs = rng.random((n, 2))
+    z = np.random.default_rng(1).standard_normal(n)
+    NN = S.find_ordered_nn_gpu(locs, m)
+    # -- neighbour arrays against the definition on sampled rows
+    for k in np.concatenate([[0, 1, 5, 29, 30, 31, 100], rng.integers(1000, n, 40)]):
+        d = np.sqrt((locs[: k + 1, 0] - locs[k, 0]) ** 2 + (locs[: k + 1, 1] - locs[k, 1]) ** 2)
+        o = np.lexsort((np.arange(k + 1), d))[: min(p, k + 1)] + 1
+        assert np.array_equal(NN[k, : len(o)], o) and not NN[k, len(o):].any()
+    revNN = NN[:, ::-1].copy()
+    revCond = np.where(revNN != 0, 0, -1).astype(np.int8)
+    revCond[:, -1] = 1
+    cp, tau = [1.0, 0.02, 1.5], 0.1
+    plan = G.Plan(locs, revNN, revCond)
+    plan.set_data(z)
+    plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_NUMERATOR | G.GPV_WANT_U)
+    s = plan.sums()
+    assert s[6] == 0 and s[7] == n
+    Lent = plan.Lentries()
+    # -- sampled conditioning sets against the oracle
+    rows = np.sort(np.concatenate([np.arange(0, 40), rng.choice(np.arange(40, n), 3000, replace=False)]))
+    sub = revNN[rows]
+    used = np.unique(sub[sub != 0]) - 1
+    remap = np.zeros(n + 1, dtype=np.int64)
+    remap[used + 1] = np.arange(1, used.size + 1)
+    Nl = max(used.size, len(rows))
+    nnp = np.zeros((Nl, p), dtype=np.int64); nnp[: len(rows)] = remap[sub]
+    cdp = np.zeros((Nl, p)); cdp[: len(rows)] = np.where(revCond[rows] < 0, 0, revCond[rows])
+    lp = np.zeros((Nl, 2)); lp[: used.size] = locs[used]
+    ref = R.U_NZentries(R.max_threads(), 1, lp, nnp, cdp, np.full(Nl, tau), np.full(1, tau), "matern", cp)
+    refL = ref["Lentries"][: len(rows)]
+    err = np.abs(Lent[rows] - refL).max(axis=1) / np.abs(refL).max(axis=1)
+    assert err.max() < ROW_TOL
+    # -- fused sums vs host recomputation from the U entries (cond.yz='z': every neighbour is observed-conditioned)
+    n0 = (revNN != 0).sum(axis=1)
+    dk = Lent[np.arange(n), n0 - 1]
+    v = 1.0 / dk ** 2
+    nb = revNN[:, :-1]
+    # left-aligned Lentries <-> right-aligned revNN: column j of Lentries pairs with revNN column (p - n0 + j)
+    ak = np.zeros(n)
+    full = n0 == p
+    ak[full] = np.einsum("ij,ij->i", Lent[full, : p - 1], z[nb[full] - 1])
+    for k in np.where(~full)[0]:
+        idx = revNN[k, p - n0[k]: p - 1] - 1
+        ak[k] = Lent[k, : n0[k] - 1] @ z[idx]
+    mu = -ak / dk
+    np.testing.assert_allclose(s[0], np.log(dk).sum(), rtol=1e-11)
+    np.testing.assert_allclose(s[1], (ak ** 2).sum(), rtol=1e-10)
+    np.testing.assert_allclose(s[2], np.log(tau + v).sum(), rtol=1e-11)
+    np.testing.assert_allclose(s[3], ((z - mu) ** 2 / (tau + v)).sum(), rtol=1e-10)
+    ll = G.loglik_z_from_sums(s, n)
+    assert abs(ll - (-0.5 * (np.log(tau + v).sum() + ((z - mu) ** 2 / (tau + v)).sum() + n * np.log(2 * np.pi)))) < 1e-9 * abs(ll)
+    # -- reproducibility and shard additivity at full size
+    plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+    s2 = plan.sums()
+    plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+    assert np.array_equal(plan.sums(), s2)                      # bitwise
+    np.testing.assert_allclose(s2[[2, 3]], s[[2, 3]], rtol=1e-13)
+    tot = np.zeros(8)
+    for a, b in ((0, 333_333), (333_333, 700_001), (700_001, n)):
+        sh = G.Plan(locs, revNN, revCond, row_begin=a, row_end=b)
+        sh.set_data(z)
+        sh.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+        tot += sh.sums()
+        del sh
+    np.testing.assert_allclose(tot[[2, 3, 7]], s2[[2, 3, 7]], rtol=1e-12)
+
+
 def test_m_equals_n_minus_1_exact_density():
     # vignette identity on the GPU path: m = n-1 => exact multivariate normal log density
     G = _need_gpu()
