@@ -45,14 +45,23 @@ def order_outsidein(locs):
     return order_middleout(locs)[::-1].copy()
 
 
-def order_maxmin_exact(locs):
+def order_maxmin_exact(locs, native=True):
     """R/ordering_functions.R:147-150 -> src/MaxMin.cpp:661-738: exact max-min distance
-    ordering, first point closest to the centroid.  O(n^2/2) definition with a running
-    min-distance vector (the reference's heap algorithm is quasi-linear; a native
-    port is a 'next' item).  Returns 1-based indices."""
+    ordering, first point closest to the centroid.  native=True: the library's quasi-linear
+    host routine (gpv_order_maxmin_exact, lazy heap + grid balls); native=False: the O(n^2)
+    definition below with a running min-distance vector (its cross-check).  Returns 1-based indices."""
     locs = np.ascontiguousarray(locs, dtype=np.float64)
     n = locs.shape[0]
-    avg = locs.sum(axis=0) / n
+    if native:
+        from . import _lib as L
+        lf = np.asfortranarray(locs)
+        out = np.empty(n, dtype=np.int32)
+        L.check(L.lib().gpv_order_maxmin_exact(L.dptr(lf), n, locs.shape[1], L.iptr(out)), "gpv_order_maxmin_exact")
+        return out.astype(np.int64)
+    avg = np.zeros(locs.shape[1])
+    for i in range(n):                      # sequential sums like src/MaxMin.cpp:679-691
+        avg += locs[i]
+    avg /= n
     first = int(np.argmin(((locs - avg) ** 2).sum(axis=1)))
     order = np.empty(n, dtype=np.int64)
     order[0] = first

@@ -195,6 +195,10 @@ int gpv_mplan_get_Lentries(gpv_mplan *mplan, double *Lentries /* Nlocs x ncolNN 
  * Cond out: n x ncolNN column-major R logical (1/0/NA_INTEGER). */
 int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t firstind_pred, int *Cond);
 
+/* Exact max-min-distance ordering, quasi-linear (host): R/ordering_functions.R:147-150 -> src/MaxMin.cpp:661-738.
+ * locs n x dim column-major; ord out: n one-based indices (first = closest to the centroid). */
+int gpv_order_maxmin_exact(const double *locs, int64_t n, int dim, int *ord);
+
 /* Exact ordered nearest neighbours on the GPU (brute force, bit-exact): the definition of R/NN_kdtree.R:73-83
  * (what GpGp::find_ordered_nn computes at R/vecchia_specify.R:159, without its random jitter).  locs: n x dim
  * column-major in the ORDERED layout; NNarray: n x (m+1) column-major, 1-based, 0 = NA; only rows

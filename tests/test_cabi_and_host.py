@@ -179,6 +179,26 @@ def test_orderings():
     assert np.array_equal(S.order_outsidein(locs), mo[::-1])
 
 
+@pytest.mark.parametrize("n,d", [(1, 2), (2, 2), (17, 1), (800, 2), (3000, 2), (1500, 3), (600, 5)])
+def test_native_maxmin_matches_definition(n, d):
+    from gpvecchia_amd import specify as S
+    from oracle import r_side as R
+    locs = np.random.default_rng(n + d).random((n, d))
+    a = S.order_maxmin_exact(locs, native=True)
+    assert np.array_equal(a, S.order_maxmin_exact(locs, native=False))
+    if n <= 1500:
+        assert np.array_equal(a, R.order_maxmin_exact(locs))
+
+
+def test_native_maxmin_grid_ties_and_clusters():
+    from gpvecchia_amd import specify as S
+    g = np.stack(np.meshgrid(np.arange(30.0), np.arange(20.0)), -1).reshape(-1, 2)     # all distances tie
+    assert np.array_equal(S.order_maxmin_exact(g, native=True), S.order_maxmin_exact(g, native=False))
+    rng = np.random.default_rng(3)
+    c = np.vstack([rng.normal(0, 1e-3, (400, 2)), rng.normal(5, 1.0, (400, 2)), np.zeros((5, 2))])   # clusters + duplicates
+    assert np.array_equal(S.order_maxmin_exact(c, native=True), S.order_maxmin_exact(c, native=False))
+
+
 def test_removeNAs_semantics():
     from gpvecchia_amd.api import _removeNAs
     z = np.array([1.0, np.nan, 3.0, 5.0])
