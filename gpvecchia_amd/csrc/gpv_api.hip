@@ -186,8 +186,8 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
 {
     if (!out) return GPV_ERR_BAD_ARG;
     *out = nullptr;
-    if (Nlocs <= 0 || dim < 1 || dim > 3 + 1000 || ncolNN < 1 || !revNN) return GPV_ERR_BAD_ARG;
-    if (dim > kMaxDimGeneric) return GPV_ERR_BAD_ARG;
+    if (Nlocs <= 0 || Nlocs >= ((int64_t)1 << 31) || dim < 1 || dim > kMaxDimGeneric || ncolNN < 1 || !revNN)
+        return GPV_ERR_BAD_ARG;
     if (row_begin < 0 || row_end > Nlocs || row_begin > row_end) return GPV_ERR_BAD_ARG;
     int ndev = 0;
     if (gpv_device_count(&ndev) != GPV_OK) return GPV_ERR_NO_DEVICE;
