@@ -43,6 +43,9 @@
 #ifndef GPV_MINW_LARGE
 #define GPV_MINW_LARGE 2      // for P > 32 (=> <= 256 VGPRs)
 #endif
+#ifndef GPV_RPL2_MAXP
+#define GPV_RPL2_MAXP 41        // two rows per lane for 24 <= P <= this (measured: -23 % at P=41, +6 % at P=51)
+#endif
 #ifndef GPV_COV_UNROLL
 #define GPV_COV_UNROLL 2       // unroll factor of the covariance rounds
 #endif
@@ -55,19 +58,19 @@ namespace gpv {
 // geometry of one conditioning set inside a wavefront
 template <int P>
 struct Geo {
-    static constexpr int RPL = (P >= 24 && P <= 32) ? 2 : 1;                    // rows per lane (measured: pays from P ~ 24)
+    static constexpr int RPL = (P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1;         // rows per lane (measured: pays from P ~ 24)
     static constexpr int LPS0 = (P + RPL - 1) / RPL;                            // lanes per set, minimal
     // one more lane per set when it costs no set per wave: guarantees a spare row slot for the data row
     static constexpr int LPS = (LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0;
     static constexpr int SLOTS = LPS * RPL;                                     // row slots per set (>= P)
     static constexpr bool ZROW = SLOTS > P;                                     // slot P carries the data row
     static constexpr int SPW = 64 / LPS;                                        // sets per wave
-    static constexpr int MINW = (P <= 32) ? GPV_MINW_SMALL : GPV_MINW_LARGE;    // launch_bounds waves/SIMD
+    static constexpr int MINW = (P <= 32) ? GPV_MINW_SMALL : (RPL == 2 ? 1 : GPV_MINW_LARGE);   // launch_bounds waves/SIMD
 };
 
 __host__ __device__ constexpr int k_lps(int P)
 {
-    const int rpl = (P >= 24 && P <= 32) ? 2 : 1;
+    const int rpl = (P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1;
     const int l0 = (P + rpl - 1) / rpl;
     return (l0 * rpl == P && l0 < 64 && 64 / (l0 + 1) == 64 / l0) ? l0 + 1 : l0;
 }
