@@ -195,6 +195,38 @@ def test_sharded_plans_add_up():
     assert abs(G.loglik_z_from_sums(tot, n) - ll_ref) <= LL_RTOL * abs(ll_ref)
 
 
+@pytest.mark.parametrize("p", [2, 3, 5, 9, 12, 17, 22, 27, 32, 33, 42, 52, 62, 64])
+def test_ragged_rows_with_holes(p):
+    # rows with missing entries ANYWHERE (not only on the left): the reference compacts the non-zero indices and pairs
+    # them with the LAST n0 entries of the cond row (src/U_NZentries.cpp:44-47); every compiled row length is hit,
+    # including the identity-padded ones (p not in the list)
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(p)
+    n, d = 400, 2
+    locs = rng.random((n, d))
+    revNN = np.zeros((n, p))
+    revCond = np.full((n, p), np.nan)
+    for k in range(n):
+        cand = rng.permutation(k)[: min(k, p - 1)] + 1
+        keep = cand[rng.random(len(cand)) < 0.8]
+        row = np.zeros(p)
+        pos = np.sort(rng.choice(p - 1, size=len(keep), replace=False)) if len(keep) else np.array([], int)
+        row[pos] = keep                                   # holes in arbitrary columns
+        row[p - 1] = k + 1                                # self last
+        revNN[k] = row
+        n0 = int((row != 0).sum())
+        c = (rng.random(n0) < 0.5).astype(float)
+        c[-1] = 1
+        revCond[k, p - n0:] = c
+    cp, tau = [1.0, 0.3, 1.5], 0.1 + rng.random(n)
+    ref = R.U_NZentries(1, n, locs, revNN, revCond, tau, tau, "matern", cp)
+    out = G.U_NZentries(1, n, locs, revNN, revCond, tau, tau, "matern", cp)
+    assert out["n_failed"] == ref["n_failed"] == 0
+    assert _row_err(out["Lentries"], ref["Lentries"]) < 1e-7          # all-latent subsets can be ill-conditioned
+    np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
+
+
 def test_multiplan_single_process_shards():
     # gpv_mplan_*: several shards driven from one host process (here all on device 0: the box has one GPU)
     G = _need_gpu()
