@@ -6,7 +6,8 @@ from ._lib import (GPV_WANT_DENOM, GPV_WANT_LOGLIK_Z, GPV_WANT_MEAN, GPV_WANT_NU
 from .api import (EsqeFun, MaternFun, MultiPlan, Plan, U2V, U_NZentries, U_NZentries_mat, createU, loglik_from_sums,  # noqa: F401
                   loglik_z_from_sums, numerator_from_sums, vecchia_likelihood, vecchia_likelihood_U, vecchia_specify)
 
-from .laplace import calculate_posterior_VL, vecchia_laplace_likelihood, vecchia_prediction  # noqa: F401,E402
+from .laplace import (calculate_posterior_VL, vecchia_laplace_likelihood,  # noqa: F401,E402
+                      vecchia_laplace_likelihood_from_posterior, vecchia_prediction)
 
 from .wrappers import vecchia_estimate  # noqa: F401,E402
 

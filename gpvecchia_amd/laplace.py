@@ -133,24 +133,33 @@ def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covpa
 
 
 # ---------------------------------------------------------------------------
-# R/vecchia_laplace_NR.R:361-416
+# R/vecchia_laplace_NR.R:361-416, :444-491
 # ---------------------------------------------------------------------------
+def vecchia_laplace_likelihood_from_posterior(z, posterior, vecchia_approx, likelihood_model=None, covparms=None,
+                                             likparms=None, covmodel="matern", y_init=None, prior_mean=None, device=0):
+    """R/vecchia_laplace_NR.R:444-491: the three log-likelihood terms from an existing calculate_posterior_VL result."""
+    z = np.asarray(z, dtype=np.float64)
+    pm = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64)
+    z_pseudo = posterior["t"] - pm                                        # :455
+    nug_pseudo = posterior["D"]
+    pseudo_marginal = A.vecchia_likelihood(z_pseudo, vecchia_approx, covparms, nug_pseudo, covmodel, device=device)   # :470-471
+    true_llh = posterior["model_llh"](posterior["mean"], z)               # :475-476
+    m = posterior["mean"] - pm
+    pseudo_cond = np.sum(-0.5 * np.log(2 * np.pi * nug_pseudo) - 0.5 * (z_pseudo - m) ** 2 / nug_pseudo)   # :479 dnorm(log=TRUE)
+    ll = pseudo_marginal - pseudo_cond + true_llh                         # :482-483
+    if y_init is None:
+        return ll
+    return dict(llv=ll, mean=posterior["mean"])
+
+
 def vecchia_laplace_likelihood(z, vecchia_approx, likelihood_model, covparms, likparms=None, covmodel="matern",
                                max_iter=50, convg=1e-5, y_init=None, prior_mean=None, device=0):
+    """R/vecchia_laplace_NR.R:361-416."""
     z = np.asarray(z, dtype=np.float64)
     post = calculate_posterior_VL(z, vecchia_approx, likelihood_model, covparms, covmodel, likparms, max_iter, convg,
                                   y_init, prior_mean, device=device)
     if not post["cnvgd"]:                                                 # :373
         warnings.warn("Convergence Failed, returning -Inf")
         return -np.inf
-    pm = post["prior_mean"]
-    z_pseudo = post["t"] - pm                                             # :381
-    nug_pseudo = post["D"]
-    pseudo_marginal = A.vecchia_likelihood(z_pseudo, vecchia_approx, covparms, nug_pseudo, covmodel, device=device)   # :396-397
-    true_llh = post["model_llh"](post["mean"], z)                         # :401-402
-    m = post["mean"] - pm
-    pseudo_cond = np.sum(-0.5 * np.log(2 * np.pi * nug_pseudo) - 0.5 * (z_pseudo - m) ** 2 / nug_pseudo)   # :405 dnorm(log=TRUE)
-    ll = pseudo_marginal - pseudo_cond + true_llh                         # :408-409
-    if y_init is None:
-        return ll
-    return dict(llv=ll, mean=post["mean"])
+    return vecchia_laplace_likelihood_from_posterior(z, post, vecchia_approx, likelihood_model, covparms, likparms,
+                                                     covmodel, y_init, post["prior_mean"], device=device)
