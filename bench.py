@@ -105,6 +105,10 @@ def main():
     ap.add_argument("--mode", choices=["L", "U", "S"], default="L",
                     help="L: fused log-likelihood, cond.yz='z' (headline); U: also materialise the U entries in HBM; "
                          "S: the reference's default cond.yz='SGV' with the posterior pass (U2V) on the GPU, 1 GPU only")
+    ap.add_argument("--config", choices=["C2", "C3", "C4"], default=None,
+                    help="BASELINE.json parity configs (SURVEY.md §8d): C2 n=1e5 m=20 d=2; C3 n=1e6 m=30 d=2 (the default, "
+                         "the configuration the metric is quoted on); C4 n=1e6 m=60 d=3 exponential")
+    ap.add_argument("--nu", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="conditioning sets in the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
@@ -127,9 +131,14 @@ def main():
 
     import gpvecchia_amd as G
 
+    if args.config == "C2":
+        args.n, args.m, args.d, args.nu = 100_000, 20, 2, 1.5
+    elif args.config == "C4":
+        args.n, args.m, args.d, args.nu = 1_000_000, 60, 3, 0.5
     n, m, d = args.n, args.m, args.d
     p = m + 1
-    covparms = [1.0, 0.02 if d == 2 else 0.05, 1.5]
+    rng_ = {("C2"): 0.05}.get(args.config, 0.02 if d == 2 else 0.05)
+    covparms = [1.0, rng_, args.nu]
     tau = 0.1
     t_setup = time.time()
     if args.mode == "S" and world > 1:
@@ -204,7 +213,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"n={n} {d}-D uniform, Matern nu=1.5, m={m}, cond.yz={'SGV' if args.mode == 'S' else 'z'}, mode {args.mode} "
+            "config": {"workload": f"n={n} {d}-D uniform, Matern nu={args.nu}, m={m}, cond.yz={'SGV' if args.mode == 'S' else 'z'}, mode {args.mode} "
                                    f"(BASELINE.json configs[2] geometry; rows sharded over {world} GPU(s))",
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
                        "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2)},
