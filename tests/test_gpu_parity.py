@@ -227,6 +227,29 @@ def test_ragged_rows_with_holes(p):
     np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
 
 
+@pytest.mark.parametrize("cp,tau", [([1.0, 1e-4, 1.5], 0.1),      # range << spacing: block ~ identity, exp underflows
+                                    ([1e6, 0.2, 1.5], 1e3),       # large variance and nugget
+                                    ([1e-8, 0.2, 0.5], 1e-9),     # tiny variance and nugget
+                                    ([1.0, 0.3, 2.5], 1e8),       # removeNAs-style huge nugget (R/vecchia_likelihood.R:55)
+                                    ([1.0, 5.0, 0.5], 1e-3)])     # range >> domain, exponential kernel stays PD
+def test_extreme_parameters(cp, tau):
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, m = 500, 20
+    locs, z, va = _case(n, m, 2, 99, "SGV")
+    ref = R.createU(va, cp, tau)["U_entries"]
+    prep = va["U_prep"]
+    out = G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], np.full(n, tau), np.full(n, tau),
+                        "matern", cp)
+    assert out["n_failed"] == ref["n_failed"] == 0
+    assert np.isfinite(out["Lentries"]).all()
+    _assert_rows_close(out["Lentries"], ref["Lentries"], va, cp, tau)
+    np.testing.assert_allclose(out["Zentries"], ref["Zentries"], rtol=1e-15)
+    pva = _to_product_va(va)
+    ll_ref = R.vecchia_likelihood(z, va, cp, tau)
+    assert abs(G.vecchia_likelihood(z, pva, cp, tau) - ll_ref) <= 1e-8 * abs(ll_ref)
+
+
 def test_multiplan_single_process_shards():
     # gpv_mplan_*: several shards driven from one host process (here all on device 0: the box has one GPU)
     G = _need_gpu()
