@@ -15,6 +15,9 @@
  *   - Status codes: 0 = ok, > 0 = error (gpv_status_string()).  A non-positive-
  *     definite block is NOT an error (reference: message on Rcerr, zero row,
  *     src/U_NZentries.cpp:64-66); it is reported through n_failed.
+ *   - Threading: every call blocks the calling host thread (or is asynchronous on the given stream); a plan may be
+ *     used from one thread at a time; different plans may be used concurrently from different threads.  The library
+ *     keeps no global state besides what HIP keeps.
  *   - The library never falls back to a CPU path: without a usable GPU every
  *     compute entry returns GPV_ERR_NO_DEVICE.
  */
