@@ -113,7 +113,9 @@ struct gpv_plan {
     int32_t *d_nn = nullptr, *d_newpos = nullptr, *d_rowid = nullptr;
     // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
     bool have_post = false;
-    int32_t *d_colptr = nullptr, *d_crow = nullptr, *d_rowptr = nullptr, *d_rcol = nullptr, *d_order = nullptr;
+    int32_t *d_colptr = nullptr, *d_crow = nullptr, *d_rowptr = nullptr, *d_rcol = nullptr, *d_order = nullptr,
+            *d_tptr = nullptr;
+    uint16_t *d_tp = nullptr;
     uint8_t *d_cslot = nullptr, *d_rslot = nullptr;
     double *d_R = nullptr, *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
            *d_post2 = nullptr, *d_zuser = nullptr;
@@ -171,7 +173,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_rowptr, pl->d_rcol, pl->d_order, pl->d_cslot, pl->d_rslot,
                     pl->d_R, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu};
+                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tptr, pl->d_tp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -416,7 +418,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         PostArgs pa;
         pa.colptr = pl->d_colptr; pa.crow = pl->d_crow; pa.cslot = pl->d_cslot;
         pa.rowptr = pl->d_rowptr; pa.rcol = pl->d_rcol; pa.rslot = pl->d_rslot;
-        pa.order = pl->d_order;
+        pa.order = pl->d_order; pa.tptr = pl->d_tptr; pa.tp = pl->d_tp;
         pa.L = pl->d_L; pa.R = pl->d_R; pa.avec = pl->d_avec; pa.z = pl->d_zuser;
         pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
         pa.nug_scalar = pl->nug_scalar;
@@ -498,15 +500,49 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     const size_t nnz = crow.size();
     std::vector<int32_t> rowptr((size_t)n + 1, 0);
     for (int64_t i = 0; i < n; ++i) rowptr[(size_t)i + 1] = rowptr[(size_t)i] + rowcnt[(size_t)i + 1];
-    std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1), rcol(nnz);
+    std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1), rcol(nnz), qof(nnz);
     std::vector<uint8_t> rslot(nnz);
     for (int64_t k = 0; k < n; ++k)                        // ascending k => every row list ascends
         for (int32_t e = colptr[(size_t)k]; e < colptr[(size_t)k + 1]; ++e) {
             const int32_t i = crow[(size_t)e];
             rcol[(size_t)fill[(size_t)i]] = (int32_t)k;
             rslot[(size_t)fill[(size_t)i]] = cslot[(size_t)e];
+            qof[(size_t)e] = fill[(size_t)i];              // row-list position of the pair (row i, column k)
             fill[(size_t)i]++;
         }
+    // match lists: for the pair q = (row k, column c > k) every entry e of column c with row r_e <= k is a row of
+    // column k as well (the latent conditioning sets of SGV are cliques; for other patterns the entry is dropped, which is
+    // the zero-fill rule); store (position of r_e in column k) | (slot of r_e in column c) << 8
+    std::vector<int32_t> tptr(nnz + 1, 0);
+    for (int64_t c = 0; c < n; ++c) {
+        const int32_t b0 = colptr[(size_t)c], cn = colptr[(size_t)c + 1] - b0;
+        for (int32_t ek = 0; ek + 1 < cn; ++ek) tptr[(size_t)qof[(size_t)(b0 + ek)] + 1] = ek + 1;   // entries 0..ek (k itself included)
+    }
+    for (size_t q = 0; q < nnz; ++q) tptr[q + 1] += tptr[q];
+    std::vector<uint16_t> tp((size_t)tptr[nnz]);
+    {
+        const int32_t *cp_ = colptr.data(), *cr_ = crow.data(), *qo_ = qof.data(), *tq_ = tptr.data();
+        const uint8_t *cs_ = cslot.data();
+        uint16_t *tp_ = tp.data();
+        parallel_for(n, [=](int64_t cb2, int64_t ce2) {
+            for (int64_t c = cb2; c < ce2; ++c) {
+                const int32_t b0 = cp_[c], cn = cp_[c + 1] - b0;
+                for (int32_t ek = 0; ek + 1 < cn; ++ek) {
+                    const int32_t k = cr_[b0 + ek];
+                    const int32_t kb = cp_[k], kn = cp_[k + 1] - kb;
+                    uint16_t *dst = tp_ + tq_[qo_[b0 + ek]];
+                    int32_t w = 0;
+                    for (int32_t e = 0; e <= ek; ++e) {
+                        const int32_t r = cr_[b0 + e];
+                        int32_t lo = 0, hi = kn;                    // position of r in column k (ascending rows)
+                        while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cr_[kb + mid] < r) lo = mid + 1; else hi = mid; }
+                        if (lo < kn && cr_[kb + lo] == r) dst[w++] = (uint16_t)(lo | ((int)cs_[b0 + e] << 8));
+                        else dst[w++] = (uint16_t)0xFFFF;           // not a row of column k: dropped (never under SGV)
+                    }
+                }
+            }
+        });
+    }
     // level of column k = 1 + max level of the columns c > k that contain row k
     std::vector<int32_t> lev((size_t)n, 0);
     int32_t maxlev = 0;
@@ -558,6 +594,8 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if ((rc = up((void **)&pl->d_rcol, rcol.data(), nnz * 4)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_rslot, rslot.data(), nnz)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_order, order.data(), order.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_tptr, tptr.data(), tptr.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_tp, tp.data(), tp.size() * 2)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     const size_t nd = sizeof(double) * (size_t)n;
     if (!pl->d_R) GPV_HIP(hipMalloc((void **)&pl->d_R, nd * pl->P));

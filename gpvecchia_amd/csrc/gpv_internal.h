@@ -68,6 +68,8 @@ struct PostArgs {
     const int32_t *rowptr;   // [n+1] row lists: columns rcol[] (ascending, first = the row itself), slots rslot[]
     const int32_t *rcol;
     const uint8_t *rslot;
+    const int32_t *tptr;     // [nnz+1] per row-list entry q = (k in column c): its match list tp[tptr[q]..tptr[q+1])
+    const uint16_t *tp;      //   one uint16 per entry of column c with row <= k: (position of that row in column k) | (slot in column c) << 8
     const int32_t *order;    // columns sorted by level
     const double *L;         // [n][ld] Lentries (values of the latent block B)
     double *R;               // [n][ld] factor values, same layout

@@ -13,15 +13,15 @@
 // and the solve R t = z2 rides along (row k of R is complete when column k is processed):
 //     z2_k = sum_{c: k in col c} B_kc a_c - z_k/tau_k ,   t_k = (z2_k - sum_{c>k} R_kc t_c) / R_kk .
 // Columns are level-scheduled (column k waits for every column c > k that contains row k); one wavefront
-// per column, lane t owns entry t of the column and merges its row list with the column's own row list.
+// per column (eight for hub columns); the row/column matching is precomputed once per plan (tptr/tp).
 #include "gpv_internal.h"
 
 namespace gpv {
 
 // Lanes own the COLUMNS c > k of row k's list (64 per round), not the rows of column k: a hub row that is
 // conditioned on by hundreds of later points is then a few wide rounds instead of one long serial merge.
-// For each of its column's entries the lane looks up the matching row of column k (binary search over the
-// wave's registers via ds_bpermute, no memory traffic) and drops the product into an LDS tile T[row][lane];
+// For each of its column's entries the lane reads the matching row of column k from the plan's match list
+// (built once on the host) and drops the product into an LDS tile T[row][lane];
 // row sums are taken in a fixed order afterwards => bitwise reproducible.
 // WPC = waves cooperating on one column: 1 in the wide early levels (one column per wave, 4 per block),
 // 8 in the narrow tail levels whose columns belong to "hub" points with row lists of hundreds to thousands
@@ -47,69 +47,56 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
     }
     const int self_slot = __shfl(my_slot, cnt - 1, 64);
     const double dk = A.L[(int64_t)k * ld + self_slot];
-    int nsteps = 0;
-    while ((1 << nsteps) < cnt + 1) ++nsteps;        // binary-search depth, wave uniform
 
     double acc = 0.0, z2 = 0.0, s = 0.0;
     for (int base = qb + 64 * ((WPC == 1) ? 0 : wib); base < qe; base += 64 * WPC) {
         const int q = base + lane;
         const bool active = q < qe;
-        int c = k, sk = 0, cb = 0, cn = 0;
+        int c = k, tb = 0, ne = 0;
         double Bk = 0.0, Rk = 0.0;
         if (active) {
             c = A.rcol[q];
-            sk = A.rslot[q];
+            const int sk = A.rslot[q];
             const int64_t o = (int64_t)c * ld + sk;
             Bk = A.L[o];
             z2 = __builtin_fma(Bk, A.avec[c], z2);
             if (c > k) {
                 Rk = A.R[o];
                 s = __builtin_fma(Rk, A.tvec[c], s);
-                cb = A.colptr[c];
-                cn = A.colptr[c + 1] - cb;
+                tb = A.tptr[q];
+                ne = A.tptr[q + 1] - tb;       // entries of column c with row <= k: all of them are rows of column k (SGV cliques)
             }
         }
         for (int t = 0; t < cnt; ++t) T[t * 65 + lane] = 0.0;
-        int maxcn = cn;
+        int maxne = ne;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const int o2 = __shfl_xor(maxcn, off, 64);
-            maxcn = o2 > maxcn ? o2 : maxcn;
+            const int o2 = __shfl_xor(maxne, off, 64);
+            maxne = o2 > maxne ? o2 : maxne;
         }
-        // the lane's column c is consumed in bursts of EC entries: all loads of a burst are independent and
-        // issued together (row ids, then slots/values of the matches), the binary searches in between are ALU only
+        // which row of column k each entry of the lane's column c pairs with was worked out when the plan was built
+        // (tp): the inner loop is two independent gathers per entry and one LDS store, in bursts of 8
         constexpr int EC = 8;
-        for (int e0 = 0; e0 < maxcn; e0 += EC) {
-            int r[EC], pos[EC];
-#pragma unroll
-            for (int u = 0; u < EC; ++u) r[u] = (e0 + u < cn) ? A.crow[cb + e0 + u] : -1;
+        for (int e0 = 0; e0 < maxne; e0 += EC) {
+            int pv[EC];
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
-                int lo = 0, hi = cnt;
-                for (int st = 0; st < nsteps; ++st) {
-                    const int mid = (lo + hi) >> 1;
-                    const int v = __shfl(my_row, mid < cnt ? mid : cnt - 1, 64);
-                    const bool go = (lo < hi) && (v < r[u]);
-                    const bool stay = (lo < hi) && !(v < r[u]);
-                    lo = go ? mid + 1 : lo;
-                    hi = stay ? mid : hi;
-                }
-                const int v = __shfl(my_row, lo < cnt ? lo : cnt - 1, 64);
-                pos[u] = (r[u] >= 0 && lo < cnt && v == r[u]) ? lo : -1;
+                const int v = (e0 + u < ne) ? (int)A.tp[tb + e0 + u] : 0xFFFF;
+                pv[u] = (v == 0xFFFF) ? -1 : v;          // 0xFFFF: the row is not in column k (never under SGV) => zero fill
             }
             double lv[EC], rv[EC];
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
                 lv[u] = 0.0; rv[u] = 0.0;
-                if (pos[u] >= 0) {
-                    const int64_t o = (int64_t)c * ld + A.cslot[cb + e0 + u];
+                if (pv[u] >= 0) {
+                    const int64_t o = (int64_t)c * ld + (pv[u] >> 8);
                     lv[u] = A.L[o];
                     rv[u] = A.R[o];
                 }
             }
 #pragma unroll
             for (int u = 0; u < EC; ++u)
-                if (pos[u] >= 0) T[pos[u] * 65 + lane] = lv[u] * Bk - rv[u] * Rk;
+                if (pv[u] >= 0) T[(pv[u] & 255) * 65 + lane] = lv[u] * Bk - rv[u] * Rk;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
