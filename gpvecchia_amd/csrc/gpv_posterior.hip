@@ -18,14 +18,18 @@
 
 namespace gpv {
 
-// Lanes own the COLUMNS c > k of row k's list (64 per round), not the rows of column k: a hub row that is
-// conditioned on by hundreds of later points is then a few wide rounds instead of one long serial merge.
-// For each of its column's entries the lane reads the matching row of column k from the plan's match list
-// (built once on the host) and drops the product into an LDS tile T[row][lane];
-// row sums are taken in a fixed order afterwards => bitwise reproducible.
+// Lanes own the COLUMNS c > k of row k's list, not the rows of column k: a hub row that is conditioned on by
+// hundreds of later points is then a sequence of wide rounds instead of one long serial merge.  A round covers
+// kRC = 16 columns with kSub = 4 lanes each (row lists average ~m/2.5 entries, so wider rounds idle most lanes
+// and their LDS tile would cap the occupancy of this latency-bound kernel); the four lanes of a column split its
+// entries.  For each entry the lane reads the matching row of column k from the plan's match list (built once
+// on the host) and drops the product into an LDS tile T[row][column]; row sums are taken in a fixed order
+// afterwards => bitwise reproducible.
 // WPC = waves cooperating on one column: 1 in the wide early levels (one column per wave, 4 per block),
 // 8 in the narrow tail levels whose columns belong to "hub" points with row lists of hundreds to thousands
-// of entries (the rounds of 64 columns are dealt round-robin to the waves, partial results meet in LDS).
+// of entries (the rounds are dealt round-robin to the waves, partial results meet in LDS).
+constexpr int kRC = 16, kSub = 4, kTS = kRC + 1;      // columns per round, lanes per column, tile row stride (doubles)
+
 template <int WPC>
 __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kernel(const PostArgs A, int first, int count)
 {
@@ -35,53 +39,50 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
     const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
     if (WPC == 1 && w >= count) return;
     const int ld = A.ld;
-    double *T = tile_all + (size_t)wib * ld * 65;
+    double *T = tile_all + (size_t)wib * ld * kTS;
     const int k = A.order[first + w];
     const int cp = A.colptr[k];
     const int cnt = A.colptr[k + 1] - cp;            // latent entries of column k, ascending rows, self (= k) last
     const int qb = A.rowptr[k], qe = A.rowptr[k + 1];  // row list of k: columns ascending, first is k itself
-    int my_row = 0x7fffffff, my_slot = 0;
-    if (lane < cnt) {
-        my_row = A.crow[cp + lane];
-        my_slot = A.cslot[cp + lane];
-    }
+    int my_slot = 0;
+    if (lane < cnt) my_slot = A.cslot[cp + lane];
     const int self_slot = __shfl(my_slot, cnt - 1, 64);
     const double dk = A.L[(int64_t)k * ld + self_slot];
+    const int col = lane >> 2, sub = lane & (kSub - 1);
+    // row-sum ownership: up to 32 rows -> two lanes per row (8 columns each), else one lane per row
+    const bool two = ld <= 32;
+    const int srow = two ? (lane & 31) : lane, shalf = two ? (lane >> 5) : 0;
 
     double acc = 0.0, z2 = 0.0, s = 0.0;
-    for (int base = qb + 64 * ((WPC == 1) ? 0 : wib); base < qe; base += 64 * WPC) {
-        const int q = base + lane;
-        const bool active = q < qe;
+    for (int base = qb + kRC * ((WPC == 1) ? 0 : wib); base < qe; base += kRC * WPC) {
+        const int q = base + col;
         int c = k, tb = 0, ne = 0;
         double Bk = 0.0, Rk = 0.0;
-        if (active) {
+        if (q < qe) {
             c = A.rcol[q];
             const int sk = A.rslot[q];
             const int64_t o = (int64_t)c * ld + sk;
             Bk = A.L[o];
-            z2 = __builtin_fma(Bk, A.avec[c], z2);
+            if (sub == 0) z2 = __builtin_fma(Bk, A.avec[c], z2);
             if (c > k) {
                 Rk = A.R[o];
-                s = __builtin_fma(Rk, A.tvec[c], s);
+                if (sub == 0) s = __builtin_fma(Rk, A.tvec[c], s);
                 tb = A.tptr[q];
                 ne = A.tptr[q + 1] - tb;       // entries of column c with row <= k: all of them are rows of column k (SGV cliques)
             }
         }
-        for (int t = 0; t < cnt; ++t) T[t * 65 + lane] = 0.0;
-        int maxne = ne;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const int o2 = __shfl_xor(maxne, off, 64);
-            maxne = o2 > maxne ? o2 : maxne;
-        }
-        // which row of column k each entry of the lane's column c pairs with was worked out when the plan was built
-        // (tp): the inner loop is two independent gathers per entry and one LDS store, in bursts of 8
+        if (__builtin_amdgcn_ballot_w64(ne > 0) == 0) continue;       // only the column itself in this round (wave uniform)
+        for (int t = lane; t < cnt * kTS; t += 64) T[t] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // entries sub, sub+4, ... of the column: one 2-byte match record, two gathers and one LDS store each, 8 in flight
         constexpr int EC = 8;
-        for (int e0 = 0; e0 < maxne; e0 += EC) {
+        for (int e0 = sub; __builtin_amdgcn_ballot_w64(e0 < ne) != 0; e0 += EC * kSub) {
             int pv[EC];
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
-                const int v = (e0 + u < ne) ? (int)A.tp[tb + e0 + u] : 0xFFFF;
+                const int e = e0 + u * kSub;
+                const int v = (e < ne) ? (int)A.tp[tb + e] : 0xFFFF;
                 pv[u] = (v == 0xFFFF) ? -1 : v;          // 0xFFFF: the row is not in column k (never under SGV) => zero fill
             }
             double lv[EC], rv[EC];
@@ -96,19 +97,25 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
             }
 #pragma unroll
             for (int u = 0; u < EC; ++u)
-                if (pv[u] >= 0) T[(pv[u] & 255) * 65 + lane] = lv[u] * Bk - rv[u] * Rk;
+                if (pv[u] >= 0) T[(pv[u] & 255) * kTS + col] = lv[u] * Bk - rv[u] * Rk;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < cnt) {
-            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0;       // fixed association => reproducible
-            for (int l = 0; l < 64; l += 4) {
-                r0 += T[lane * 65 + l];
-                r1 += T[lane * 65 + l + 1];
-                r2 += T[lane * 65 + l + 2];
-                r3 += T[lane * 65 + l + 3];
+        {
+            double r0 = 0.0, r1 = 0.0;                            // fixed association => reproducible
+            if (srow < cnt) {
+                const double *tr = T + srow * kTS + shalf * 8;
+                if (two) {
+                    r0 = (tr[0] + tr[1]) + (tr[2] + tr[3]);
+                    r1 = (tr[4] + tr[5]) + (tr[6] + tr[7]);
+                } else {
+                    r0 = ((tr[0] + tr[1]) + (tr[2] + tr[3])) + ((tr[4] + tr[5]) + (tr[6] + tr[7]));
+                    r1 = ((tr[8] + tr[9]) + (tr[10] + tr[11])) + ((tr[12] + tr[13]) + (tr[14] + tr[15]));
+                }
             }
-            acc += (r0 + r1) + (r2 + r3);
+            double r = r0 + r1;
+            if (two) r += __shfl_xor(r, 32, 64);                  // both halves end with the same bits (a+b == b+a)
+            acc += r;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -147,19 +154,13 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
-    if (count <= 128 && a.ld <= 32) {                 // narrow tail level: 8 waves per column
-        const size_t smem = (size_t)8 * a.ld * 65 * sizeof(double);
-        static bool attr_set = false;
-        if (!attr_set) {                              // > 64 KiB of dynamic LDS needs the opt-in
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-            attr_set = true;
-        }
+    if (count <= 128) {                               // narrow tail level: 8 waves per column
+        const size_t smem = (size_t)8 * a.ld * kTS * sizeof(double);
         hipLaunchKernelGGL(gpv_posterior_level_kernel<8>, dim3(count), dim3(512), smem, s, a, first, count);
         return hipGetLastError();
     }
-    const int wpb = a.ld <= 32 ? 4 : 2;
-    const size_t smem = (size_t)wpb * a.ld * 65 * sizeof(double);
+    const int wpb = 4;
+    const size_t smem = (size_t)wpb * a.ld * kTS * sizeof(double);
     hipLaunchKernelGGL(gpv_posterior_level_kernel<1>, dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count);
     return hipGetLastError();
 }
