@@ -65,7 +65,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
                      [f"-DGPV_INST_P={P}"] + extra_flags, hdrs, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), [], hdrs, force))
     work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), [], hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), [], hdrs, force))
+    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), hdrs, force))
     work.append((os.path.join(CSRC, "gpv_order.cpp"), os.path.join(BUILD, "order.o"), ["-x", "c++"], hdrs, force))
     work.append((os.path.join(CSRC, "gpv_nn.hip"), os.path.join(BUILD, "nn.o"), ["-ffp-contract=off"], hdrs, force))
     jobs = jobs or min(8, os.cpu_count() or 1)

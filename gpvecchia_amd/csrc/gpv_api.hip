@@ -113,10 +113,10 @@ struct gpv_plan {
     int32_t *d_nn = nullptr, *d_newpos = nullptr, *d_rowid = nullptr;
     // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
     bool have_post = false;
-    int32_t *d_colptr = nullptr, *d_crow = nullptr, *d_rowptr = nullptr, *d_rcol = nullptr, *d_order = nullptr,
-            *d_tptr = nullptr;
+    int32_t *d_colptr = nullptr, *d_crow = nullptr;
+    int4 *d_colrec = nullptr, *d_rowrec = nullptr;
     uint16_t *d_tp = nullptr;
-    uint8_t *d_cslot = nullptr, *d_rslot = nullptr;
+    uint8_t *d_cslot = nullptr;
     double *d_R = nullptr, *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
            *d_post2 = nullptr, *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
@@ -171,9 +171,9 @@ int gpv_plan_destroy(gpv_plan *pl)
     if (pl->stream) (void)hipStreamSynchronize(pl->stream);
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
-                    pl->d_colptr, pl->d_crow, pl->d_rowptr, pl->d_rcol, pl->d_order, pl->d_cslot, pl->d_rslot,
+                    pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_R, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tptr, pl->d_tp};
+                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -417,8 +417,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     if (flags & GPV_WANT_DENOM) {
         PostArgs pa;
         pa.colptr = pl->d_colptr; pa.crow = pl->d_crow; pa.cslot = pl->d_cslot;
-        pa.rowptr = pl->d_rowptr; pa.rcol = pl->d_rcol; pa.rslot = pl->d_rslot;
-        pa.order = pl->d_order; pa.tptr = pl->d_tptr; pa.tp = pl->d_tp;
+        pa.colrec = pl->d_colrec; pa.rowrec = pl->d_rowrec; pa.tp = pl->d_tp;
         pa.L = pl->d_L; pa.R = pl->d_R; pa.avec = pl->d_avec; pa.z = pl->d_zuser;
         pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
         pa.nug_scalar = pl->nug_scalar;
@@ -560,6 +559,21 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     for (int32_t l = 0; l <= maxlev; ++l) pl->levptr[(size_t)l + 1] += pl->levptr[(size_t)l];
     std::vector<int32_t> pos(pl->levptr.begin(), pl->levptr.end() - 1), order((size_t)n);
     for (int64_t k = n - 1; k >= 0; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
+    // longest row lists first inside a level (they bound the level's duration)
+    for (int32_t l = 0; l <= maxlev; ++l)
+        std::stable_sort(order.begin() + pl->levptr[(size_t)l], order.begin() + pl->levptr[(size_t)l + 1],
+                         [&](int32_t a, int32_t b) {
+                             return rowptr[(size_t)a + 1] - rowptr[(size_t)a] > rowptr[(size_t)b + 1] - rowptr[(size_t)b];
+                         });
+    std::vector<int4> colrec(2 * (size_t)n), rowrec(nnz);
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t k = order[(size_t)i];
+        const int32_t b0 = colptr[(size_t)k], cn = colptr[(size_t)k + 1] - b0;
+        colrec[2 * (size_t)i] = make_int4(k, b0, cn, rowptr[(size_t)k]);
+        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], (int)cslot[(size_t)(b0 + cn - 1)], 0, 0);
+    }
+    for (size_t q = 0; q < nnz; ++q)
+        rowrec[q] = make_int4(rcol[q], tptr[q], (int)rslot[q] | ((tptr[q + 1] - tptr[q]) << 8), 0);
 
     // second schedule for the posterior mean (R^T u = t): column k waits for the rows i < k it contains
     std::vector<int32_t> lev2((size_t)n, 0);
@@ -590,11 +604,8 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if ((rc = up((void **)&pl->d_colptr, colptr.data(), colptr.size() * 4)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_crow, crow.data(), nnz * 4)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_cslot, cslot.data(), nnz)) != GPV_OK) return rc;
-    if ((rc = up((void **)&pl->d_rowptr, rowptr.data(), rowptr.size() * 4)) != GPV_OK) return rc;
-    if ((rc = up((void **)&pl->d_rcol, rcol.data(), nnz * 4)) != GPV_OK) return rc;
-    if ((rc = up((void **)&pl->d_rslot, rslot.data(), nnz)) != GPV_OK) return rc;
-    if ((rc = up((void **)&pl->d_order, order.data(), order.size() * 4)) != GPV_OK) return rc;
-    if ((rc = up((void **)&pl->d_tptr, tptr.data(), tptr.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_colrec, colrec.data(), colrec.size() * sizeof(int4))) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_rowrec, rowrec.data(), rowrec.size() * sizeof(int4))) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_tp, tp.data(), tp.size() * 2)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     const size_t nd = sizeof(double) * (size_t)n;

@@ -65,12 +65,14 @@ struct PostArgs {
     const int32_t *colptr;   // [n+1] latent entries of column k: rows crow[], slots cslot[] (slot = position in Lentries row k)
     const int32_t *crow;
     const uint8_t *cslot;
-    const int32_t *rowptr;   // [n+1] row lists: columns rcol[] (ascending, first = the row itself), slots rslot[]
-    const int32_t *rcol;
-    const uint8_t *rslot;
-    const int32_t *tptr;     // [nnz+1] per row-list entry q = (k in column c): its match list tp[tptr[q]..tptr[q+1])
-    const uint16_t *tp;      //   one uint16 per entry of column c with row <= k: (position of that row in column k) | (slot in column c) << 8
-    const int32_t *order;    // columns sorted by level
+    // level-ordered column records {k, colptr[k], entries, rowptr[k], rowptr[k+1], slot of the diagonal, 0, 0} and
+    // row-list records, one per pair q = (row k, column c) with c ascending and the first c = k itself:
+    // {c, first match record, slot of row k in column c | (match records) << 8, 0}; the match records
+    // tp[first..first+count) hold, for each entry of column c with row <= k, (position of that row in column k) |
+    // (its slot in column c) << 8.  One dependent load less per hop than walking rowptr/rcol/rslot/tptr.
+    const int4 *colrec;      // [n][2]
+    const int4 *rowrec;      // [nnz]
+    const uint16_t *tp;
     const double *L;         // [n][ld] Lentries (values of the latent block B)
     double *R;               // [n][ld] factor values, same layout
     const double *avec;      // [n] a_k

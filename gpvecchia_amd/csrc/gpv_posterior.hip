@@ -28,6 +28,12 @@ namespace gpv {
 // WPC = waves cooperating on one column: 1 in the wide early levels (one column per wave, 4 per block),
 // 8 in the narrow tail levels whose columns belong to "hub" points with row lists of hundreds to thousands
 // of entries (the rounds are dealt round-robin to the waves, partial results meet in LDS).
+#ifndef GPV_POST_EC
+#define GPV_POST_EC 4
+#endif
+#ifndef GPV_POST_WIDE
+#define GPV_POST_WIDE 2048
+#endif
 constexpr int kRC = 16, kSub = 4, kTS = kRC + 1;      // columns per round, lanes per column, tile row stride (doubles)
 
 template <int WPC>
@@ -40,14 +46,13 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
     if (WPC == 1 && w >= count) return;
     const int ld = A.ld;
     double *T = tile_all + (size_t)wib * ld * kTS;
-    const int k = A.order[first + w];
-    const int cp = A.colptr[k];
-    const int cnt = A.colptr[k + 1] - cp;            // latent entries of column k, ascending rows, self (= k) last
-    const int qb = A.rowptr[k], qe = A.rowptr[k + 1];  // row list of k: columns ascending, first is k itself
+    const int4 c0 = A.colrec[2 * (size_t)(first + w)], c1 = A.colrec[2 * (size_t)(first + w) + 1];
+    const int k = c0.x, cp = c0.y;
+    const int cnt = c0.z;                            // latent entries of column k, ascending rows, self (= k) last
+    const int qb = c0.w, qe = c1.x;                  // row list of k: columns ascending, first is k itself
+    const double dk = A.L[(int64_t)k * ld + c1.y];
     int my_slot = 0;
     if (lane < cnt) my_slot = A.cslot[cp + lane];
-    const int self_slot = __shfl(my_slot, cnt - 1, 64);
-    const double dk = A.L[(int64_t)k * ld + self_slot];
     const int col = lane >> 2, sub = lane & (kSub - 1);
     // row-sum ownership: up to 32 rows -> two lanes per row (8 columns each), else one lane per row
     const bool two = ld <= 32;
@@ -59,16 +64,16 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
         int c = k, tb = 0, ne = 0;
         double Bk = 0.0, Rk = 0.0;
         if (q < qe) {
-            c = A.rcol[q];
-            const int sk = A.rslot[q];
-            const int64_t o = (int64_t)c * ld + sk;
+            const int4 rr = A.rowrec[q];
+            c = rr.x;
+            const int64_t o = (int64_t)c * ld + (rr.z & 255);
             Bk = A.L[o];
             if (sub == 0) z2 = __builtin_fma(Bk, A.avec[c], z2);
-            if (c > k) {
+            ne = rr.z >> 8;                    // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
+            tb = rr.y;
+            if (ne > 0) {
                 Rk = A.R[o];
                 if (sub == 0) s = __builtin_fma(Rk, A.tvec[c], s);
-                tb = A.tptr[q];
-                ne = A.tptr[q + 1] - tb;       // entries of column c with row <= k: all of them are rows of column k (SGV cliques)
             }
         }
         if (__builtin_amdgcn_ballot_w64(ne > 0) == 0) continue;       // only the column itself in this round (wave uniform)
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // entries sub, sub+4, ... of the column: one 2-byte match record, two gathers and one LDS store each, 8 in flight
-        constexpr int EC = 8;
+        constexpr int EC = GPV_POST_EC;
         for (int e0 = sub; __builtin_amdgcn_ballot_w64(e0 < ne) != 0; e0 += EC * kSub) {
             int pv[EC];
 #pragma unroll
@@ -154,7 +159,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
-    if (count <= 128) {                               // narrow tail level: 8 waves per column
+    if (count <= GPV_POST_WIDE) {                             // narrow tail level: 8 waves per column
         const size_t smem = (size_t)8 * a.ld * kTS * sizeof(double);
         hipLaunchKernelGGL(gpv_posterior_level_kernel<8>, dim3(count), dim3(512), smem, s, a, first, count);
         return hipGetLastError();
