@@ -64,7 +64,7 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
         work.append((os.path.join(CSRC, "gpv_sets_inst.hip"), os.path.join(BUILD, f"sets_p{P}.o"),
                      [f"-DGPV_INST_P={P}"] + extra_flags, hdrs, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), [], hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), [], hdrs, force))
+    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), hdrs, force))
     work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), hdrs, force))
     work.append((os.path.join(CSRC, "gpv_order.cpp"), os.path.join(BUILD, "order.o"), ["-x", "c++"], hdrs, force))
     work.append((os.path.join(CSRC, "gpv_nn.hip"), os.path.join(BUILD, "nn.o"), ["-ffp-contract=off"], hdrs, force))

@@ -114,10 +114,13 @@ struct gpv_plan {
     // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
     bool have_post = false;
     int32_t *d_colptr = nullptr, *d_crow = nullptr;
+    int32_t *d_ccol = nullptr;
     int4 *d_colrec = nullptr, *d_rowrec = nullptr;
-    uint16_t *d_tp = nullptr;
+    uint8_t *d_tp = nullptr;
+    double2 *d_C = nullptr;
+    int64_t post_nnz = 0;
     uint8_t *d_cslot = nullptr;
-    double *d_R = nullptr, *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
+    double *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
            *d_post2 = nullptr, *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
     int32_t *d_order2 = nullptr;
@@ -172,7 +175,7 @@ int gpv_plan_destroy(gpv_plan *pl)
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
-                    pl->d_R, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser,
+                    pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser,
                     pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -416,12 +419,14 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
     if (flags & GPV_WANT_DENOM) {
         PostArgs pa;
-        pa.colptr = pl->d_colptr; pa.crow = pl->d_crow; pa.cslot = pl->d_cslot;
+        pa.colptr = pl->d_colptr; pa.crow = pl->d_crow;
         pa.colrec = pl->d_colrec; pa.rowrec = pl->d_rowrec; pa.tp = pl->d_tp;
-        pa.L = pl->d_L; pa.R = pl->d_R; pa.avec = pl->d_avec; pa.z = pl->d_zuser;
+        pa.C = pl->d_C; pa.z = pl->d_zuser;
         pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
         pa.nug_scalar = pl->nug_scalar;
         pa.tvec = pl->d_tvec; pa.logr = pl->d_logr; pa.ld = pl->P;
+        GPV_HIP(launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot, pl->Nlocs,
+                                         pl->post_nnz, pl->d_C, st));
         for (size_t lv = 0; lv + 1 < pl->levptr.size(); ++lv)
             GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], st));
         GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_post2, st));
@@ -511,32 +516,38 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
         }
     // match lists: for the pair q = (row k, column c > k) every entry e of column c with row r_e <= k is a row of
     // column k as well (the latent conditioning sets of SGV are cliques; for other patterns the entry is dropped, which is
-    // the zero-fill rule); store (position of r_e in column k) | (slot of r_e in column c) << 8
+    // the zero-fill rule); store the position of r_e in column k (the entries of a column are kept in ascending row
+    // order in the compact blocks, so e itself addresses the value)
     std::vector<int32_t> tptr(nnz + 1, 0);
     for (int64_t c = 0; c < n; ++c) {
         const int32_t b0 = colptr[(size_t)c], cn = colptr[(size_t)c + 1] - b0;
         for (int32_t ek = 0; ek + 1 < cn; ++ek) tptr[(size_t)qof[(size_t)(b0 + ek)] + 1] = ek + 1;   // entries 0..ek (k itself included)
     }
+    if ((int64_t)nnz + n >= ((int64_t)1 << 31)) return GPV_ERR_BAD_ARG;       // 32-bit offsets into the compact blocks
+    {
+        int64_t total = 0;
+        for (size_t q = 0; q < nnz; ++q) total += tptr[q + 1];
+        if (total >= ((int64_t)1 << 31)) return GPV_ERR_BAD_ARG;              // 32-bit offsets into the match records
+    }
     for (size_t q = 0; q < nnz; ++q) tptr[q + 1] += tptr[q];
-    std::vector<uint16_t> tp((size_t)tptr[nnz]);
+    std::vector<uint8_t> tp((size_t)tptr[nnz]);
     {
         const int32_t *cp_ = colptr.data(), *cr_ = crow.data(), *qo_ = qof.data(), *tq_ = tptr.data();
-        const uint8_t *cs_ = cslot.data();
-        uint16_t *tp_ = tp.data();
+        uint8_t *tp_ = tp.data();
         parallel_for(n, [=](int64_t cb2, int64_t ce2) {
             for (int64_t c = cb2; c < ce2; ++c) {
                 const int32_t b0 = cp_[c], cn = cp_[c + 1] - b0;
                 for (int32_t ek = 0; ek + 1 < cn; ++ek) {
                     const int32_t k = cr_[b0 + ek];
                     const int32_t kb = cp_[k], kn = cp_[k + 1] - kb;
-                    uint16_t *dst = tp_ + tq_[qo_[b0 + ek]];
+                    uint8_t *dst = tp_ + tq_[qo_[b0 + ek]];
                     int32_t w = 0;
                     for (int32_t e = 0; e <= ek; ++e) {
                         const int32_t r = cr_[b0 + e];
                         int32_t lo = 0, hi = kn;                    // position of r in column k (ascending rows)
                         while (lo < hi) { const int32_t mid = (lo + hi) >> 1; if (cr_[kb + mid] < r) lo = mid + 1; else hi = mid; }
-                        if (lo < kn && cr_[kb + lo] == r) dst[w++] = (uint16_t)(lo | ((int)cs_[b0 + e] << 8));
-                        else dst[w++] = (uint16_t)0xFFFF;           // not a row of column k: dropped (never under SGV)
+                        if (lo < kn && cr_[kb + lo] == r) dst[w++] = (uint8_t)lo;
+                        else dst[w++] = (uint8_t)0xFF;              // not a row of column k: dropped (never under SGV)
                     }
                 }
             }
@@ -569,11 +580,18 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     for (int64_t i = 0; i < n; ++i) {
         const int32_t k = order[(size_t)i];
         const int32_t b0 = colptr[(size_t)k], cn = colptr[(size_t)k + 1] - b0;
-        colrec[2 * (size_t)i] = make_int4(k, b0, cn, rowptr[(size_t)k]);
-        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], (int)cslot[(size_t)(b0 + cn - 1)], 0, 0);
+        colrec[2 * (size_t)i] = make_int4(k, b0 + k, cn, rowptr[(size_t)k]);
+        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], 0, 0, 0);
     }
-    for (size_t q = 0; q < nnz; ++q)
-        rowrec[q] = make_int4(rcol[q], tptr[q], (int)rslot[q] | ((tptr[q + 1] - tptr[q]) << 8), 0);
+    std::vector<int32_t> ccol(nnz);
+    for (int64_t c = 0; c < n; ++c) {
+        const int32_t b0 = colptr[(size_t)c], cn = colptr[(size_t)c + 1] - b0;
+        for (int32_t e = 0; e < cn; ++e) {
+            const size_t q = (size_t)qof[(size_t)(b0 + e)];               // the pair (row crow[b0+e], column c)
+            rowrec[q] = make_int4(b0 + (int32_t)c, tptr[q], e | ((e + 1 < cn ? e + 1 : 0) << 8), 0);
+            ccol[(size_t)(b0 + e)] = (int32_t)c;
+        }
+    }
 
     // second schedule for the posterior mean (R^T u = t): column k waits for the rows i < k it contains
     std::vector<int32_t> lev2((size_t)n, 0);
@@ -606,10 +624,13 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if ((rc = up((void **)&pl->d_cslot, cslot.data(), nnz)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_colrec, colrec.data(), colrec.size() * sizeof(int4))) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_rowrec, rowrec.data(), rowrec.size() * sizeof(int4))) != GPV_OK) return rc;
-    if ((rc = up((void **)&pl->d_tp, tp.data(), tp.size() * 2)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_tp, tp.data(), tp.size())) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_ccol, ccol.data(), nnz * 4)) != GPV_OK) return rc;
+    if (pl->d_C) { (void)hipFree(pl->d_C); pl->d_C = nullptr; }
+    GPV_HIP(hipMalloc((void **)&pl->d_C, sizeof(double2) * (nnz + (size_t)n)));
+    pl->post_nnz = (int64_t)nnz;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     const size_t nd = sizeof(double) * (size_t)n;
-    if (!pl->d_R) GPV_HIP(hipMalloc((void **)&pl->d_R, nd * pl->P));
     if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
     if (!pl->d_tvec) GPV_HIP(hipMalloc((void **)&pl->d_tvec, nd));
     if (!pl->d_logr) GPV_HIP(hipMalloc((void **)&pl->d_logr, nd));

@@ -61,28 +61,34 @@ hipError_t launch_covfun(const double *dist, int64_t n, int cov, double sig0, do
 // ---- posterior ("U2V") pass for cond.yz='SGV': sparse UL factor of W = U_y U_y^T on the pattern of the latent
 // block of U (zero fill for SGV), fused with the triangular solve; R/vecchia_prediction.R:62-83,
 // R/vecchia_likelihood.R:85-90.  All index arrays are in ORDERING index space.
+//
+// The pass is bound by gather traffic (every column is re-read by each of its rows' columns, at a different
+// level each time), so the latent entries live in a COMPACT block array C of (B, R) pairs: column c owns
+//     C[cb]        = (a_c, t_c)                     cb = colptr[c] + c
+//     C[cb+1+e]    = (B_ec, R_ec)   e = 0..cnt-1    rows ascending, the diagonal last
+// and the pair (row k, column c) needs exactly the contiguous prefix C[cb .. cb+1+e_k].
 struct PostArgs {
-    const int32_t *colptr;   // [n+1] latent entries of column k: rows crow[], slots cslot[] (slot = position in Lentries row k)
+    const int32_t *colptr;   // [n+1] latent entries of column k: rows crow[] ascending (used by the mean pass)
     const int32_t *crow;
-    const uint8_t *cslot;
-    // level-ordered column records {k, colptr[k], entries, rowptr[k], rowptr[k+1], slot of the diagonal, 0, 0} and
-    // row-list records, one per pair q = (row k, column c) with c ascending and the first c = k itself:
-    // {c, first match record, slot of row k in column c | (match records) << 8, 0}; the match records
-    // tp[first..first+count) hold, for each entry of column c with row <= k, (position of that row in column k) |
-    // (its slot in column c) << 8.  One dependent load less per hop than walking rowptr/rcol/rslot/tptr.
+    // level-ordered column records {k, cb, entries, rowptr[k], rowptr[k+1], 0, 0, 0} and row-list records, one per
+    // pair q = (row k, column c) with c ascending and the first c = k itself:
+    // {cb of column c, first match record, e_k | (match records) << 8, 0}; the match records
+    // tp[first..first+count) hold, for entries e = 0..e_k of column c, the position of that row in column k
+    // (0xFF: not a row of column k, dropped = the zero-fill rule; never under SGV).
     const int4 *colrec;      // [n][2]
     const int4 *rowrec;      // [nnz]
-    const uint16_t *tp;
-    const double *L;         // [n][ld] Lentries (values of the latent block B)
-    double *R;               // [n][ld] factor values, same layout
-    const double *avec;      // [n] a_k
+    const uint8_t *tp;
+    double2 *C;              // [nnz + n] compact blocks
     const double *z;         // [n] ordered data
     const double *nuggets;   // [n] ordered nuggets or nullptr
     double nug_scalar;
     double *tvec;            // [n] solution of R t = z2
     double *logr;            // [n] log R_kk
-    int ld;
+    int ld;                  // row length of Lentries (bounds the entries per column)
 };
+// C <- (Lentries, a): ccol/cslot give column and Lentries slot of every compact entry
+hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
+                                    const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C, hipStream_t s);
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s);
 // posterior mean (R/vecchia_prediction.R:118-126): solve R^T u = t column by column in ASCENDING dependency
 // order (order2), mu_ord = -u

@@ -44,65 +44,60 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
     const int wib = threadIdx.x >> 6;
     const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
     if (WPC == 1 && w >= count) return;
-    const int ld = A.ld;
-    double *T = tile_all + (size_t)wib * ld * kTS;
+    double *T = tile_all + (size_t)wib * A.ld * kTS;
     const int4 c0 = A.colrec[2 * (size_t)(first + w)], c1 = A.colrec[2 * (size_t)(first + w) + 1];
-    const int k = c0.x, cp = c0.y;
+    const int k = c0.x;
     const int cnt = c0.z;                            // latent entries of column k, ascending rows, self (= k) last
     const int qb = c0.w, qe = c1.x;                  // row list of k: columns ascending, first is k itself
-    const double dk = A.L[(int64_t)k * ld + c1.y];
-    int my_slot = 0;
-    if (lane < cnt) my_slot = A.cslot[cp + lane];
+    double2 *Ck = A.C + c0.y;                        // the column's own block
+    const double dk = Ck[cnt].x;
     const int col = lane >> 2, sub = lane & (kSub - 1);
     // row-sum ownership: up to 32 rows -> two lanes per row (8 columns each), else one lane per row
-    const bool two = ld <= 32;
+    const bool two = A.ld <= 32;
     const int srow = two ? (lane & 31) : lane, shalf = two ? (lane >> 5) : 0;
 
     double acc = 0.0, z2 = 0.0, s = 0.0;
     for (int base = qb + kRC * ((WPC == 1) ? 0 : wib); base < qe; base += kRC * WPC) {
         const int q = base + col;
-        int c = k, tb = 0, ne = 0;
+        int tb = 0, ne = 0;
+        const double2 *Cc = A.C;
         double Bk = 0.0, Rk = 0.0;
         if (q < qe) {
             const int4 rr = A.rowrec[q];
-            c = rr.x;
-            const int64_t o = (int64_t)c * ld + (rr.z & 255);
-            Bk = A.L[o];
-            if (sub == 0) z2 = __builtin_fma(Bk, A.avec[c], z2);
+            Cc = A.C + rr.x;
+            const double2 head = Cc[0], own = Cc[1 + (rr.z & 255)];     // (a_c, t_c), (B_kc, R_kc)
+            Bk = own.x;
+            if (sub == 0) z2 = __builtin_fma(Bk, head.x, z2);
             ne = rr.z >> 8;                    // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
             tb = rr.y;
             if (ne > 0) {
-                Rk = A.R[o];
-                if (sub == 0) s = __builtin_fma(Rk, A.tvec[c], s);
+                Rk = own.y;
+                if (sub == 0) s = __builtin_fma(Rk, head.y, s);
             }
         }
         if (__builtin_amdgcn_ballot_w64(ne > 0) == 0) continue;       // only the column itself in this round (wave uniform)
         for (int t = lane; t < cnt * kTS; t += 64) T[t] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // entries sub, sub+4, ... of the column: one 2-byte match record, two gathers and one LDS store each, 8 in flight
+        // entries sub, sub+4, ... of the column: one match byte, one 16-byte (B, R) gather and one LDS store each
         constexpr int EC = GPV_POST_EC;
         for (int e0 = sub; __builtin_amdgcn_ballot_w64(e0 < ne) != 0; e0 += EC * kSub) {
             int pv[EC];
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
                 const int e = e0 + u * kSub;
-                const int v = (e < ne) ? (int)A.tp[tb + e] : 0xFFFF;
-                pv[u] = (v == 0xFFFF) ? -1 : v;          // 0xFFFF: the row is not in column k (never under SGV) => zero fill
+                const int v = (e < ne) ? (int)A.tp[tb + e] : 0xFF;
+                pv[u] = (v == 0xFF) ? -1 : v;            // 0xFF: the row is not in column k (never under SGV) => zero fill
             }
-            double lv[EC], rv[EC];
+            double2 br[EC];
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
-                lv[u] = 0.0; rv[u] = 0.0;
-                if (pv[u] >= 0) {
-                    const int64_t o = (int64_t)c * ld + (pv[u] >> 8);
-                    lv[u] = A.L[o];
-                    rv[u] = A.R[o];
-                }
+                br[u] = make_double2(0.0, 0.0);
+                if (pv[u] >= 0) br[u] = Cc[1 + e0 + u * kSub];
             }
 #pragma unroll
             for (int u = 0; u < EC; ++u)
-                if (pv[u] >= 0) T[(pv[u] & 255) * kTS + col] = lv[u] * Bk - rv[u] * Rk;
+                if (pv[u] >= 0) T[pv[u] * kTS + col] = br[u].x * Bk - br[u].y * Rk;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -144,16 +139,39 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 512) gpv_posterior_level_kern
             s += part[v][65];
         }
     }
-    if (lane < cnt) acc = __builtin_fma(A.L[(int64_t)k * ld + my_slot], dk, acc);      // c == k term: B_ik d_k
+    if (lane < cnt) acc = __builtin_fma(Ck[1 + lane].x, dk, acc);      // c == k term: B_ik d_k
     const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
     const double accd = __shfl(acc, cnt - 1, 64) + 1.0 / tau;
     const double rkk = sqrt(accd);
-    if (lane < cnt) A.R[(int64_t)k * ld + my_slot] = (lane == cnt - 1) ? rkk : acc / rkk;
+    if (lane < cnt) Ck[1 + lane].y = (lane == cnt - 1) ? rkk : acc / rkk;
     if (lane == 0) {
         z2 -= A.z[k] / tau;                          // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
-        A.tvec[k] = (z2 - s) / rkk;
+        const double t = (z2 - s) / rkk;
+        Ck[0].y = t;
+        A.tvec[k] = t;
         A.logr[k] = log(rkk);
     }
+}
+
+// C <- (B, 0) from the row-major Lentries, heads <- (a, 0): one thread per compact entry, coalesced writes
+__global__ void __launch_bounds__(256) gpv_posterior_compact_kernel(const double *L, int ld, const double *avec,
+                                                                    const int32_t *colptr, const int32_t *ccol,
+                                                                    const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nnz; g += stride) {
+        const int c = ccol[g];
+        C[g + c + 1] = make_double2(L[(int64_t)c * ld + cslot[g]], 0.0);
+    }
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride)
+        C[(int64_t)colptr[c] + c] = make_double2(avec[c], 0.0);
+}
+hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
+                                    const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C, hipStream_t s)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gpv_posterior_compact_kernel, dim3(4096), dim3(256), 0, s, L, ld, avec, colptr, ccol, cslot, n, nnz, C);
+    return hipGetLastError();
 }
 
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s)
@@ -183,7 +201,7 @@ __global__ void __launch_bounds__(256) gpv_mean_level_kernel(const PostArgs A, c
     double part = 0.0, rkk = 1.0;
     if (lane < cnt) {
         const int i = A.crow[cp + lane];
-        const double r = A.R[(int64_t)k * A.ld + A.cslot[cp + lane]];
+        const double r = A.C[(int64_t)cp + k + 1 + lane].y;
         if (lane == cnt - 1) rkk = r; else part = r * u[i];
     }
 #pragma unroll
