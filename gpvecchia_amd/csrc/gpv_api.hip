@@ -121,7 +121,7 @@ struct gpv_plan {
     int64_t post_nnz = 0;
     uint8_t *d_cslot = nullptr;
     double *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
-           *d_post2 = nullptr, *d_zuser = nullptr;
+           *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
     int32_t *d_order2 = nullptr;
     double *d_u = nullptr, *d_mu = nullptr;
@@ -175,7 +175,7 @@ int gpv_plan_destroy(gpv_plan *pl)
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
-                    pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_post2, pl->d_zuser,
+                    pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
@@ -429,8 +429,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                                          pl->post_nnz, pl->d_C, st));
         for (size_t lv = 0; lv + 1 < pl->levptr.size(); ++lv)
             GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], st));
-        GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_post2, st));
-        GPV_HIP(launch_patch_denominator(pl->d_post2, pl->d_sums, d_sums_out, st));
+        GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st));
         if (flags & GPV_WANT_MEAN) {
             for (size_t lv = 0; lv + 1 < pl->levptr2.size(); ++lv)
                 GPV_HIP(launch_mean_level(pa, pl->d_order2, pl->d_u, pl->levptr2[lv], pl->levptr2[lv + 1] - pl->levptr2[lv], st));
@@ -637,7 +636,6 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if (!pl->d_u) GPV_HIP(hipMalloc((void **)&pl->d_u, nd));
     if (!pl->d_mu) GPV_HIP(hipMalloc((void **)&pl->d_mu, nd));
     if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 512));
-    if (!pl->d_post2) GPV_HIP(hipMalloc((void **)&pl->d_post2, sizeof(double) * 2));
     if (!pl->d_L) GPV_HIP(hipMalloc((void **)&pl->d_L, nd * pl->P));
     pl->have_post = true;
     return GPV_OK;

@@ -104,21 +104,6 @@ hipError_t launch_scatter(const double *src, const int32_t *pos, int64_t n, doub
     return hipGetLastError();
 }
 
-// sums[2] = log det W = 2 sum log R_kk, sums[3] = quadform.denom (posterior pass), mirrored to sums_copy
-__global__ void gpv_patch_denominator_kernel(const double *post2, double *sums, double *sums_copy)
-{
-    if (threadIdx.x == 0) {
-        const double a = 2.0 * post2[0], b = post2[1];
-        sums[2] = a; sums[3] = b;
-        if (sums_copy != nullptr) { sums_copy[2] = a; sums_copy[3] = b; }
-    }
-}
-hipError_t launch_patch_denominator(const double *post2, double *sums, double *sums_copy, hipStream_t s)
-{
-    hipLaunchKernelGGL(gpv_patch_denominator_kernel, dim3(1), dim3(64), 0, s, post2, sums, sums_copy);
-    return hipGetLastError();
-}
-
 // src/U_NZentries.cpp:111-115: Z[2i] = -1/sqrt(tau_i), Z[2i+1] = +1/sqrt(tau_i)
 __global__ void gpv_zentries_kernel(const double *nug, int64_t n, double *Z)
 {

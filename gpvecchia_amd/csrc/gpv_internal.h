@@ -94,8 +94,9 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipSt
 // order (order2), mu_ord = -u
 hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u, int first, int count, hipStream_t s);
 hipError_t launch_negate(const double *src, double *dst, int64_t n, hipStream_t s);
-// out[0] = sum x[i], out[1] = sum y[i]^2, fixed order (n <= 2^31)
-hipError_t launch_patch_denominator(const double *post2, double *sums, double *sums_copy, hipStream_t s);
-hipError_t launch_sum_pair(const double *x, const double *y, int64_t n, double *partials, double *out, hipStream_t s);
+// sums[2] = 2 sum x[i] (log det W from log R_kk), sums[3] = sum y[i]^2 (quadform.denom), fixed order; mirrored to
+// sums_copy when given
+hipError_t launch_sum_pair(const double *x, const double *y, int64_t n, double *partials, double *sums, double *sums_copy,
+                           hipStream_t s);
 
 }  // namespace gpv

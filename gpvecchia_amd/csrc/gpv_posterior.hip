@@ -252,19 +252,32 @@ __global__ void __launch_bounds__(256) gpv_sum_pair_stage1(const double *x, cons
         partials[2 * blockIdx.x + 1] = sy[0];
     }
 }
-__global__ void __launch_bounds__(64) gpv_sum_pair_stage2(const double *partials, int nb, double *out)
+// second stage, fused with the patch of the likelihood sums: sums[2] = log det W = 2 sum log R_kk,
+// sums[3] = quadform.denom = sum t_k^2 (mirrored to sums_copy); 4 partials per lane, then a fixed tree
+__global__ void __launch_bounds__(64) gpv_sum_pair_stage2(const double *partials, int nb, double *sums, double *sums_copy)
 {
-    if (threadIdx.x < 2) {
-        double s = 0.0;
-        for (int b = 0; b < nb; ++b) s += partials[2 * b + threadIdx.x];
-        out[threadIdx.x] = s;
+    double sx = 0.0, sy = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        sx += partials[2 * b];
+        sy += partials[2 * b + 1];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sx += __shfl_down(sx, off, 64);
+        sy += __shfl_down(sy, off, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double a = 2.0 * sx;
+        sums[2] = a; sums[3] = sy;
+        if (sums_copy != nullptr) { sums_copy[2] = a; sums_copy[3] = sy; }
     }
 }
-hipError_t launch_sum_pair(const double *x, const double *y, int64_t n, double *partials, double *out, hipStream_t s)
+hipError_t launch_sum_pair(const double *x, const double *y, int64_t n, double *partials, double *sums, double *sums_copy,
+                           hipStream_t s)
 {
     const int nb = 256;
     hipLaunchKernelGGL(gpv_sum_pair_stage1, dim3(nb), dim3(256), 0, s, x, y, n, partials);
-    hipLaunchKernelGGL(gpv_sum_pair_stage2, dim3(1), dim3(64), 0, s, partials, nb, out);
+    hipLaunchKernelGGL(gpv_sum_pair_stage2, dim3(1), dim3(64), 0, s, partials, nb, sums, sums_copy);
     return hipGetLastError();
 }
 
