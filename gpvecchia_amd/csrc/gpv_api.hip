@@ -428,7 +428,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         GPV_HIP(launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot, pl->Nlocs,
                                          pl->post_nnz, pl->d_C, st));
         for (size_t lv = 0; lv + 1 < pl->levptr.size(); ++lv)
-            GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], st));
+            GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st));
         GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st));
         if (flags & GPV_WANT_MEAN) {
             for (size_t lv = 0; lv + 1 < pl->levptr2.size(); ++lv)

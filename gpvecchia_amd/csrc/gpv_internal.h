@@ -89,7 +89,8 @@ struct PostArgs {
 // C <- (Lentries, a): ccol/cslot give column and Lentries slot of every compact entry
 hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
                                     const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C, hipStream_t s);
-hipError_t launch_posterior_level(const PostArgs &a, int first, int count, hipStream_t s);
+// columns [first, first+count) of the level-ordered records; leaves = the level's row lists hold the column only (level 0)
+hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, hipStream_t s);
 // posterior mean (R/vecchia_prediction.R:118-126): solve R^T u = t column by column in ASCENDING dependency
 // order (order2), mu_ord = -u
 hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u, int first, int count, hipStream_t s);
