@@ -220,6 +220,29 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
     return (r2 == 0.0) ? sig0 : v;
 }
 
+// the same for the closed-form families without the dist == 0 select (5 VALU ops per pair): the squared distance
+// is clamped at the smallest normal number instead, where every closed form returns sigma^2 exactly
+// (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
+template <int COV>
+__device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB)
+{
+    if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
+    r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
+    const double dist = sqrt_pos(r2);
+    if constexpr (COV == COV_MATERN15) {
+        const double t = dist * cA;
+        const double e = exp_neg(t);
+        return sA * __builtin_fma(t, e, e);
+    } else if constexpr (COV == COV_MATERN05) {
+        return sA * exp_neg(dist * cA);
+    } else if constexpr (COV == COV_MATERN25) {
+        const double t = dist * cA;
+        return sA * exp_neg(t) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
+    } else {
+        return __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));
+    }
+}
+
 template <int P, int D, int COV>
 __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_sets_kernel(const SetArgs A)
 {
@@ -373,8 +396,92 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 }
             }
         };
-        if (all_valid) cov_rounds(std::false_type{});            // wave-uniform: the common case has no padding
-        else cov_rounds(std::true_type{});
+        // Fixed-dimension, formula covariances: the same rounds without predicates.  Row slots that own no row (spare
+        // slots, idle lanes) and, for even P, the surplus half of the last round shadow a pair some other lane owns:
+        // same operands, same instruction sequence => the same bits to the same address, so every lane runs every
+        // round and the body is one basic block (loads of the next pair overlap the arithmetic of this one).
+        // Addresses: with rt = r(r+1)/2 the pair (r, r+s) lives at rt + r(s+1) + s(s+1)/2 if r+s < P, else (it wraps
+        // to j = r+s-P < r) at rt + j; the constant s(s+1)/2 rides in the instruction's offset field.
+        auto cov_rounds_fast = [&](auto masked_tag) {
+            constexpr bool MASKED = decltype(masked_tag)::value;
+            constexpr int DS = Lds::DS, DD = (D == 0) ? 1 : D;
+            // 32-bit byte offsets inside the set's LDS slices (24-bit multiplies: one v_mad_u32_u24 per address)
+            const char *xyb = reinterpret_cast<const char *>(&L.xy[sub][0][0]);
+            char *trb = reinterpret_cast<char *>(&L.tri[sub][0]);
+            int rq[RPL];
+            bool vq[RPL];
+            double xq[RPL][DD];
+            unsigned xoA[RPL], xoB[RPL], rq8[RPL], rt8[RPL], rtB8[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const bool own = lane_on && row[q] < P;
+                rq[q] = own ? row[q] : 0;                               // shadows row 0 of the set
+#pragma unroll
+                for (int t = 0; t < D; ++t) xq[q][t] = own ? xi[q][t] : L.xy[sub][0][t];
+                vq[q] = own ? valid[q] : (bool)((vmask[0] >> (sub * LPS)) & 1ull);
+                xoA[q] = __umul24(rq[q], DS * 8);
+                xoB[q] = xoA[q] - P * DS * 8;
+                rq8[q] = rq[q] * 8;
+                rt8[q] = __umul24(rq[q], rq[q] + 1) * 4;
+                rtB8[q] = rt8[q] + rq8[q];
+            }
+            auto fetch = [&](int q, int s, double (&dst)[DD]) {
+                const double *xj = reinterpret_cast<const double *>(xyb + ((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * DS * 8);
+#pragma unroll
+                for (int t = 0; t < D; ++t) dst[t] = xj[t];
+            };
+            // the partner coordinates of round s+1 are fetched before the values of round s are stored (the compiler
+            // cannot move an LDS read above an LDS write on its own), and the RPL pairs of a round are independent
+            // chains the scheduler interleaves
+            double xn[RPL][DD];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) fetch(q, 1, xn[q]);
+#pragma unroll
+            for (int s = 1; s <= H; ++s) {
+                double xc[RPL][DD];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+#pragma unroll
+                    for (int t = 0; t < D; ++t) xc[q][t] = xn[q][t];
+                    if (s < H) fetch(q, s + 1, xn[q]);
+                }
+                double v[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    double r2 = 0.0;
+#pragma unroll
+                    for (int t = 0; t < D; ++t) {
+                        const double df = xq[q][t] - xc[q][t];
+                        r2 = __builtin_fma(df, df, r2);
+                    }
+                    v[q] = cov_closed<COV>(r2, sig0, sA, cA, sB, cB);
+                    if constexpr (MASKED) {                          // padded rows/cols -> identity
+                        const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
+                        bool jvalid = false;
+#pragma unroll
+                        for (int q2 = 0; q2 < RPL; ++q2) {
+                            const int jl = j - q2 * LPS;
+                            if (jl >= 0 && jl < LPS) jvalid = (vmask[q2] >> (sub * LPS + jl)) & 1ull;
+                        }
+                        v[q] = (vq[q] && jvalid) ? v[q] : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const int cs = s * (s + 1) / 2;                  // compile-time after unrolling
+                    const unsigned oA = __umul24(rq8[q], s + 1) + rt8[q];
+                    const unsigned oB = rtB8[q] + (unsigned)(8 * (s - P - cs));
+                    *reinterpret_cast<double *>(trb + ((rq[q] < P - s) ? oA : oB) + 8 * cs) = v[q];
+                }
+            }
+        };
+        if constexpr (D != 0 && COV != COV_DENSE) {
+            if (all_valid) cov_rounds_fast(std::false_type{});   // wave-uniform: the common case has no padding
+            else cov_rounds_fast(std::true_type{});
+        } else {
+            if (all_valid) cov_rounds(std::false_type{});
+            else cov_rounds(std::true_type{});
+        }
 
         // ---- diagonal, data row staging, then the lane's rows into registers -----------------
         double a[RPL][P];
