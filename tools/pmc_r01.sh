@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/pmc_r01
 python3 tools/kbench.py --child --configs 30x2 --iters 1 > /dev/null 2>&1   # warm NN cache
 for i in 1 2 3 4; do
   case $i in
@@ -7,6 +8,6 @@ for i in 1 2 3 4; do
    3) C="GRBM_GUI_ACTIVE FETCH_SIZE";;
    4) C="WRITE_SIZE SQ_INST_CYCLES_VMEM";;
   esac
-  rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_r01/p$i -- python3 tools/kbench.py --child --configs 30x2 --iters 1 > gpurun_out/pmc_r01/log$i.txt 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d gpurun_out/pmc_r01/p$i -- python3 tools/kbench.py --child --configs 30x2 --iters 1 > gpurun_out/pmc_r01/log$i.txt 2>&1
 done
 ls -R gpurun_out/pmc_r01 | head -30
