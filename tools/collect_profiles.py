@@ -1,0 +1,61 @@
+"""Developer tool: turn the scratch output of tools/profile_round.sh (gpurun_out/<tag>/) into the tracked artefacts under
+profiles/: <name>_bench.json, <name>_kernel_stats.csv, <name>_pmc_pass<i>.csv (set-kernel rows only), <name>_pmc_summary.json
+and r01_pmc_traffic.json (the per-launch HBM traffic bench.py quotes).
+
+    python tools/collect_profiles.py gpurun_out/r01f r01_final
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, name = sys.argv[1], sys.argv[2]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = os.path.join(ROOT, "profiles")
+line = [l for l in open(os.path.join(src, "bench.json")).read().splitlines() if l.startswith("{")][-1]
+open(os.path.join(P, name + "_bench.json"), "w").write(line + "\n")
+st = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    shutil.copy(st[0], os.path.join(P, name + "_kernel_stats.csv"))
+tot = {}
+for i in (1, 2, 3, 4):
+    fs = glob.glob(os.path.join(src, f"pmc{i}", "**", "*counter_collection.csv"), recursive=True)
+    if not fs:
+        continue
+    rows = list(csv.DictReader(open(fs[0])))
+    keep = [r for r in rows if "gpv_sets_kernel" in r["Kernel_Name"]]
+    with open(os.path.join(P, f"{name}_pmc_pass{i}.csv"), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+    last = max(int(r["Dispatch_Id"]) for r in keep)
+    for r in keep:
+        if int(r["Dispatch_Id"]) == last:
+            tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+b = json.loads(line)
+nsets = b["config"]["n"]
+if "GRBM_GUI_ACTIVE" in tot:
+    cyc = tot["GRBM_GUI_ACTIVE"] / 8
+    tot["_derived"] = {
+        "kernel_cycles": cyc,
+        "valu_busy_frac": tot.get("SQ_ACTIVE_INST_VALU", 0) * 4 / 1024 / cyc,
+        "lds_busy_frac": tot.get("SQ_LDS_IDX_ACTIVE", 0) / 256 / cyc,
+        "lds_conflict_frac": tot.get("SQ_LDS_BANK_CONFLICT", 0) / max(tot.get("SQ_LDS_IDX_ACTIVE", 1), 1),
+        "valu_insts_per_set": tot.get("SQ_INSTS_VALU", 0) / nsets,
+        "fetch_bytes": tot.get("FETCH_SIZE", 0) * 1024,
+        "write_bytes": tot.get("WRITE_SIZE", 0) * 1024,
+    }
+json.dump(tot, open(os.path.join(P, name + "_pmc_summary.json"), "w"), indent=1)
+if "FETCH_SIZE" in tot:
+    json.dump({
+        "hbm_bytes_per_launch": (tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0)) * 1024,
+        "fetch_size_kb": tot["FETCH_SIZE"], "write_size_kb": tot.get("WRITE_SIZE", 0),
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), last launch of the set kernel in bench.py at "
+                "n=1e6 m=30 mode L; raw counter x 1024 B, NOT doubled: the gfx950 x2 correction is calibrated for wide "
+                "coalesced streams only, this kernel mixes a 155 MB coalesced index/flag stream with 32-byte gathers served "
+                "by L2/Infinity Cache",
+    }, open(os.path.join(P, "r01_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(tot.get("_derived", {}), indent=1))
+print(line[:400])
