@@ -55,6 +55,12 @@ class Plan:
         L.check(L.lib().gpv_plan_posterior_levels(self._h, C.byref(nl)), "gpv_plan_posterior_levels")
         return int(nl.value)
 
+    def posterior_levels(self):
+        """Number of levels of the posterior pass's schedule (after build_posterior)."""
+        nl = C.c_int()
+        L.check(L.lib().gpv_plan_posterior_levels(self._h, C.byref(nl)), "gpv_plan_posterior_levels")
+        return int(nl.value)
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) is not None and self._h.value:

@@ -15,6 +15,7 @@
 // Columns are level-scheduled (column k waits for every column c > k that contains row k); one wavefront
 // per column (eight for hub columns); the row/column matching is precomputed once per plan (tptr/tp).
 #include "gpv_internal.h"
+#include <atomic>
 
 namespace gpv {
 
@@ -209,12 +210,15 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool 
     }
     if (count <= GPV_POST_WIDE16) {                           // narrowest levels: 16 waves per column (all rounds in flight)
         const size_t smem = (size_t)16 * a.ld * kTS * sizeof(double);
-        if (smem > 64 * 1024) {
-            static bool attr_set = false;
-            if (!attr_set) {                                  // > 64 KiB of dynamic LDS needs the opt-in
+        if (smem > 64 * 1024) {                               // > 64 KiB of dynamic LDS needs the opt-in, once per device
+            static std::atomic<unsigned long long> done{0ull};
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            const unsigned long long bit = 1ull << (dev & 63);
+            if (!(done.load(std::memory_order_relaxed) & bit)) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
-                attr_set = true;
+                done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
         hipLaunchKernelGGL(gpv_posterior_level_kernel<16>, dim3(count), dim3(1024), smem, s, a, first, count);

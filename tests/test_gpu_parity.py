@@ -378,7 +378,8 @@ def test_general_nu_through_the_hot_path(nu, cond):
 
 
 @pytest.mark.parametrize("n,m,d,ordering", [(400, 8, 2, "maxmin"), (1500, 20, 2, "none"), (900, 30, 2, "maxmin"),
-                                             (700, 12, 3, "none"), (300, 5, 1, "coord")])
+                                             (700, 12, 3, "none"), (300, 5, 1, "coord"),
+                                             (600, 45, 2, "maxmin"), (500, 63, 2, "none")])   # rows longer than 32
 def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
     # default cond.yz='SGV': U, numerator and the posterior pass (U2V: R/vecchia_prediction.R:62-83) on the GPU
     G = _need_gpu()
@@ -408,6 +409,27 @@ def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
     ll2 = G.vecchia_likelihood(z, va, cp, 0.1)
     U_obj = G.createU(va, cp, 0.1)
     assert abs(ll2 - G.vecchia_likelihood_U(z, U_obj)) <= 1e-9 * abs(ll2)
+
+
+def test_sgv_posterior_pass_wide_levels():
+    # n large enough that the early levels of the schedule hold > 2048 columns (one wave per column) next to the
+    # 8- and 16-wave narrow levels and the leaf level: the device posterior pass against the sparse host
+    # factorisation (scipy) of the same U
+    G = _need_gpu()
+    n, m = 60_000, 20
+    rng = np.random.default_rng(5)
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    cp = [1.2, 0.01, 1.5]
+    tau = 0.1 + 0.1 * rng.random(n)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    plan = va[("_plan", 0)]
+    assert plan.has_posterior and plan.posterior_levels() > 40
+    s1 = plan.sums().copy()
+    ll_host = G.vecchia_likelihood_U(z, G.createU(va, cp, tau))
+    assert abs(ll - ll_host) <= 1e-9 * abs(ll_host)
+    # bitwise reproducible
+    assert G.vecchia_likelihood(z, va, cp, tau) == ll and np.array_equal(plan.sums(), s1)
 
 
 @pytest.mark.parametrize("cond", ["SGV", "z"])
