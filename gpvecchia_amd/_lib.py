@@ -30,7 +30,7 @@ EXPORTS = [
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
     "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
-    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact",
+    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
 ]
 
@@ -90,6 +90,7 @@ def lib():
     L.gpv_mplan_eval.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, i64, C.c_int, dp]
     L.gpv_mplan_get_Lentries.argtypes = [vp, dp]
     L.gpv_order_maxmin_exact.argtypes = [dp, i64, C.c_int, ip]
+    L.gpv_ic0.argtypes = [i64, ip, ip, dp, C.POINTER(C.c_int64)]
     L.gpv_find_ordered_nn.argtypes = [C.c_int, dp, i64, C.c_int, C.c_int, i64, i64, ip]
     L.gpv_whichCondOnLatent.argtypes = [ip, i64, C.c_int, i64, ip]
     _lib = L

@@ -330,6 +330,15 @@ def _plan_for(va, device=0):
     return va[key]
 
 
+def _device_nuggets(va, nug):
+    """Nugget argument of Plan.eval: a length-1 array when the nugget is constant (it then travels in the launch
+    arguments), else the n-vector in ordering (R/createU.R:75-77)."""
+    nug = np.atleast_1d(np.asarray(nug, dtype=np.float64))
+    if nug.size == 1 or np.all(nug == nug[0]):
+        return nug[:1]
+    return nug[va["ord"] - 1]
+
+
 def _ordered_nuggets(va, nuggets, n):
     """R/createU.R:73-78 for the all-observed, non-'zy' case."""
     nug = np.atleast_1d(np.asarray(nuggets, dtype=np.float64))
@@ -419,6 +428,20 @@ def _removeNAs(z, nuggets):
     return z, nug
 
 
+def ichol_lower(Wrev):
+    """R/ichol.R:16-59 -> src/ic0.cpp:43-64 through the native gpv_ic0: the lower IC(0) factor (CSR) of a sparse SPD
+    matrix on its own pattern."""
+    import scipy.sparse as sp
+    Lw = sp.tril(Wrev, format="csr")
+    Lw.sort_indices()
+    ptrs = np.ascontiguousarray(Lw.indptr, dtype=np.int32)
+    inds = np.ascontiguousarray(Lw.indices, dtype=np.int32)
+    vals = np.ascontiguousarray(Lw.data, dtype=np.float64).copy()
+    nbad = C.c_int64(0)
+    L.check(L.lib().gpv_ic0(Lw.shape[0], L.iptr(ptrs), L.iptr(inds), L.dptr(vals), C.byref(nbad)), "gpv_ic0")
+    return sp.csr_matrix((vals, inds, ptrs), shape=Lw.shape)
+
+
 def U2V(U_obj):
     """R/vecchia_prediction.R:62-83 (non-'zy', general ordering): V = t(chol(rev(U_y U_y^T))).
     Host-side (the reference runs CHOLMOD here; sequential sparse factorisation).
@@ -431,7 +454,28 @@ def U2V(U_obj):
     nW = W.shape[0]
     rev = np.arange(nW - 1, -1, -1)
     Wrev = W[rev][:, rev].tocsc()
+    if U_obj.get("ic0", False):                                             # R/vecchia_prediction.R:76-77
+        return _TriFactor(ichol_lower(Wrev))
     return spla.splu(Wrev, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+
+
+class _TriFactor:
+    """V.ord = t(ichol(W.rev)) with the two members vecchia_likelihood_U / vecchia_mean_host use of a SuperLU object:
+    `U.diagonal()` such that sum(log) = log det, and `solve` = (V V^T)^{-1}."""
+
+    def __init__(self, V):
+        self.V = V.tocsr()
+        d = V.diagonal()
+
+        class _D:
+            def diagonal(self_inner):
+                return d * d
+        self.U = _D()
+
+    def solve(self, b):
+        import scipy.sparse.linalg as spla
+        y = spla.spsolve_triangular(self.V, np.asarray(b, dtype=np.float64), lower=True)
+        return spla.spsolve_triangular(self.V.T.tocsr(), y, lower=False)
 
 
 def vecchia_mean_host(z, U_obj):
@@ -478,20 +522,16 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
     if va["cond_yz"] in ("z", "false") and isinstance(covmodel, str) and not np.any(nug == 0):
         plan = _plan_for(va, device)
         plan.set_data(z[va["ord_z"] - 1])
-        nug_all_ord, _, nugf = _ordered_nuggets(va, nug, n)
-        plan.eval(covmodel, covparms, nug_all_ord if nugf.size > 1 and not np.all(nugf == nugf[0]) else nugf[:1],
-                  GPV_WANT_LOGLIK_Z)
+        plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_LOGLIK_Z)
         return loglik_z_from_sums(plan.sums(), n)
-    if va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0) and not va.get("ic0", False):
+    if va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0):     # ic0 changes nothing: no fill
         # default mode: U, the numerator AND the posterior pass (U2V) on the GPU; SGV has no fill, so the
         # fixed-pattern factorisation equals the reference's Matrix::chol (R/vecchia_prediction.R:80)
         plan = _plan_for(va, device)
         if not plan.has_posterior:
             plan.build_posterior()
         plan.set_data(z[va["ord_z"] - 1])
-        nug_all_ord, _, nugf = _ordered_nuggets(va, nug, n)
-        plan.eval(covmodel, covparms, nug_all_ord if nugf.size > 1 and not np.all(nugf == nugf[0]) else nugf[:1],
-                  GPV_WANT_DENOM)
+        plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_DENOM)
         return loglik_from_sums(plan.sums(), n)
     U_obj = createU(va, covparms, nug, covmodel, device=device)
     return vecchia_likelihood_U(z, U_obj)

@@ -130,3 +130,39 @@ extern "C" int gpv_order_maxmin_exact(const double *locs, int64_t n, int dim, in
     }
     return GPV_OK;
 }
+
+// ---- IC(0): up-looking, row by row --------------------------------------------------------------------------
+// L_ij = (A_ij - sum_{k<j, k in row i and row j} L_ik L_jk) / L_jj ,  L_ii = sqrt(A_ii - sum_{k<i} L_ik^2)
+// on the stored pattern only (src/ic0.cpp:43-64).  Rows are finished in order, so row j < i is final when row i
+// reads it; the two sorted index lists are merged.
+extern "C" int gpv_ic0(int64_t N, const int *ptrs, const int *inds, double *vals, int64_t *n_bad)
+{
+    if (N < 0 || !ptrs || (N > 0 && (!inds || !vals))) return GPV_ERR_BAD_ARG;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int b = ptrs[i], e = ptrs[i + 1];
+        if (e <= b || inds[e - 1] != (int)i) return GPV_ERR_INDEX;           // the diagonal closes every row
+        for (int p = b; p < e; ++p) {
+            const int j = inds[p];
+            if (j < 0 || j > (int)i || (p > b && inds[p - 1] >= j)) return GPV_ERR_INDEX;
+            const int jb = ptrs[j], je = ptrs[j + 1] - 1;                     // row j without its diagonal
+            double dot = 0.0;
+            int u = b, v = jb;
+            while (u < p && v < je) {                                         // columns < j common to rows i and j
+                const int cu = inds[u], cv = inds[v];
+                if (cu == cv) dot += vals[u++] * vals[v++];
+                else if (cu < cv) ++u;
+                else ++v;
+            }
+            if (j < (int)i) {
+                vals[p] = (vals[p] - dot) / vals[je];
+            } else {
+                const double d = vals[p] - dot;
+                if (!(d > 0.0)) ++bad;
+                vals[p] = std::sqrt(d);
+            }
+        }
+    }
+    if (n_bad) *n_bad = bad;
+    return GPV_OK;
+}

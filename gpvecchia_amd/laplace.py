@@ -74,9 +74,7 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         if not plan.has_posterior:
             plan.build_posterior()
         plan.set_data(z[va["ord_z"] - 1])
-        nug_all_ord, _, nugf = A._ordered_nuggets(va, nug, n)
-        plan.eval(covmodel, covparms, nug_all_ord if nugf.size > 1 and not np.all(nugf == nugf[0]) else nugf[:1],
-                  GPV_WANT_MEAN)
+        plan.eval(covmodel, covparms, A._device_nuggets(va, nug), GPV_WANT_MEAN)
         mu_ord = plan.posterior_mean()
     else:
         U_obj = A.createU(va, covparms, nug, covmodel, device=device)

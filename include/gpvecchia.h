@@ -202,6 +202,15 @@ int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t fir
  * locs n x dim column-major; ord out: n one-based indices (first = closest to the centroid). */
 int gpv_order_maxmin_exact(const double *locs, int64_t n, int dim, int *ord);
 
+/* Zero-fill incomplete Cholesky IC(0) of a sparse SPD matrix, in place on its lower triangle in compressed-row form
+ * (equivalently the upper triangle in compressed-column form): replaces src/ic0.cpp:43-64 (`ic0`), which
+ * R/ichol.R:54 calls and U2V uses when the approximation was specified with ic0 = TRUE (R/vecchia_prediction.R:76-77).
+ * ptrs: N+1 row starts (0-based); inds: column index of every stored entry, ascending inside a row, the diagonal last;
+ * vals: the matrix entries on input, the factor L (A ~ L L^T on the pattern) on output.
+ * Returns GPV_ERR_INDEX for a malformed structure; *n_bad (may be NULL) counts non-positive pivots (NaN rows, like the
+ * reference's sqrt of a negative number). */
+int gpv_ic0(int64_t N, const int *ptrs, const int *inds, double *vals, int64_t *n_bad);
+
 /* Exact ordered nearest neighbours on the GPU (brute force, bit-exact): the definition of R/NN_kdtree.R:73-83
  * (what GpGp::find_ordered_nn computes at R/vecchia_specify.R:159, without its random jitter).  locs: n x dim
  * column-major in the ORDERED layout; NNarray: n x (m+1) column-major, 1-based, 0 = NA; only rows

@@ -428,11 +428,57 @@ def createU(va, covparms, nuggets, covmodel="matern"):
                 triplets=(prep["colindices"].copy(), prep["rowpointers"].copy(), vals))
 
 
+def ic0(ptrs, inds, vals):
+    """src/ic0.cpp:43-64 (with dot_prod, :16-31): zero-fill incomplete Cholesky on a lower triangle in compressed-row
+    form (indices ascending, diagonal last), literal loops."""
+    vals = np.array(vals, dtype=np.float64)
+    N = len(ptrs) - 1
+    for i in range(N):
+        for j in range(ptrs[i], ptrs[i + 1]):
+            l1, u1 = ptrs[i], ptrs[i + 1] - 2
+            l2, u2 = ptrs[inds[j]], ptrs[inds[j] + 1] - 2
+            dp = 0.0
+            while l1 <= u1 and l2 <= u2:                            # dot_prod
+                if inds[l1] == inds[l2]:
+                    dp += vals[l1] * vals[l2]
+                    l1 += 1; l2 += 1
+                elif inds[l1] < inds[l2]:
+                    l1 += 1
+                else:
+                    l2 += 1
+            if inds[j] < i:
+                vals[j] = (vals[j] - dp) / vals[ptrs[inds[j] + 1] - 1]
+            else:
+                vals[j] = np.sqrt(vals[j] - dp)
+    return vals
+
+
+def ichol(M):
+    """R/ichol.R:16-59 without a pattern matrix: IC(0) on the pattern of M; returns the UPPER factor (dense)."""
+    M = np.asarray(M, dtype=np.float64)
+    n = M.shape[0]
+    ptrs, inds, vals = [0], [], []
+    for c in range(n):                                              # upper triangle by columns == lower by rows
+        for r in range(c + 1):
+            if M[r, c] != 0.0:
+                inds.append(r); vals.append(M[r, c])
+        ptrs.append(len(inds))
+    v = ic0(ptrs, inds, vals)
+    R_ = np.zeros((n, n))
+    for c in range(n):
+        for p in range(ptrs[c], ptrs[c + 1]):
+            R_[inds[p], c] = v[p]
+    return R_
+
+
 def U2V(U_obj):
-    """R/vecchia_prediction.R:62-83 (non-zy, non-obspred): V = t(chol(rev(U_y U_y^T)))."""
+    """R/vecchia_prediction.R:62-83 (non-zy, non-obspred): V = t(chol(rev(U_y U_y^T))), or t(ichol(.)) when the
+    approximation was specified with ic0 = TRUE (:76-77)."""
     Uy = U_obj["U"][U_obj["latent"], :]
     W = Uy @ Uy.T                                                   # :74
     Wrev = W[::-1, ::-1]                                            # :75
+    if U_obj.get("ic0", False):
+        return ichol(Wrev).T                                        # :77
     return np.linalg.cholesky(Wrev)                                 # :80 (lower = t(upper chol))
 
 

@@ -221,3 +221,30 @@ def test_host_likelihood_U_matches_oracle():
         Uo = R.createU(vb, [1.0, 0.2, 1.5], 0.1)
         U_obj = dict(U=sp.csc_matrix(Uo["U"]), latent=Uo["latent"], ord_z=Uo["ord_z"])
         assert G.vecchia_likelihood_U(z, U_obj) == pytest.approx(R.vecchia_likelihood_U(z, Uo), rel=1e-11)
+
+
+def test_ic0_native_matches_reference_restatement():
+    # src/ic0.cpp:43-64 (called by R/ichol.R:54; U2V with ic0 = TRUE, R/vecchia_prediction.R:76-77)
+    import ctypes as C
+    import scipy.sparse as sp
+    from gpvecchia_amd import _lib as L
+    from gpvecchia_amd import api as A
+    from oracle import r_side as R
+    rng = np.random.default_rng(3)
+    n = 60
+    B = sp.random(n, n, density=0.08, random_state=4, format="csr")
+    M = (B @ B.T + sp.identity(n) * 2.0).tocsr()
+    ref_upper = R.ichol(M.toarray())                                  # upper factor, dense
+    Lw = A.ichol_lower(M.tocsc())
+    np.testing.assert_allclose(Lw.toarray(), ref_upper.T, rtol=1e-13, atol=1e-14)
+    assert np.array_equal(Lw.toarray() != 0, np.tril(M.toarray()) != 0)          # zero fill: the pattern is kept
+    # full pattern => IC(0) is the Cholesky factor
+    D = rng.standard_normal((12, 12)); S = D @ D.T + 12 * np.eye(12)
+    np.testing.assert_allclose(A.ichol_lower(sp.csc_matrix(S)).toarray(), np.linalg.cholesky(S), rtol=1e-12)
+    # malformed structure (diagonal missing) is an error, not a crash
+    ptrs = np.array([0, 1, 2], dtype=np.int32); inds = np.array([0, 0], dtype=np.int32); vals = np.ones(2)
+    assert L.lib().gpv_ic0(2, L.iptr(ptrs), L.iptr(inds), L.dptr(vals), None) == 8          # GPV_ERR_INDEX (include/gpvecchia.h)
+    # a non-positive pivot is counted
+    ptrs = np.array([0, 1, 3], dtype=np.int32); inds = np.array([0, 0, 1], dtype=np.int32)
+    vals = np.array([1.0, 2.0, 1.0]); nbad = C.c_int64(0)
+    assert L.lib().gpv_ic0(2, L.iptr(ptrs), L.iptr(inds), L.dptr(vals), C.byref(nbad)) == 0 and nbad.value == 1

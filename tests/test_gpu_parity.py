@@ -411,6 +411,34 @@ def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
     assert abs(ll2 - G.vecchia_likelihood_U(z, U_obj)) <= 1e-9 * abs(ll2)
 
 
+def test_ic0_option_of_U2V():
+    # vecchia_specify(..., ic0 = TRUE): U2V uses the zero-fill factor of W.rev (R/vecchia_prediction.R:76-77).
+    # cond.yz = 'y' has fill, so the likelihood changes and must match the restatement of src/ic0.cpp; SGV has none.
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, m = 300, 8
+    locs, z, vb = _case(n, m, 2, 31, "y")
+    cp, tau = [1.2, 0.2, 1.5], 0.15
+    vb["ic0"] = True
+    ll_ref = R.vecchia_likelihood(z, vb, cp, tau)
+    vb["ic0"] = False
+    ll_exact = R.vecchia_likelihood(z, vb, cp, tau)
+    assert abs(ll_ref - ll_exact) > 1e-6 * abs(ll_exact)              # the approximation is visible here
+    va = _to_product_va(vb)
+    va["ic0"] = True
+    assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)
+    va["ic0"] = False
+    assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_exact) <= LL_RTOL * abs(ll_exact)
+    locs, z, vs = _case(n, m, 2, 32, "SGV")
+    vs["ic0"] = True
+    ll_sgv = R.vecchia_likelihood(z, vs, cp, tau)
+    vs["ic0"] = False
+    assert abs(ll_sgv - R.vecchia_likelihood(z, vs, cp, tau)) <= 1e-12 * abs(ll_sgv)     # no fill under SGV
+    va = _to_product_va(vs)
+    va["ic0"] = True
+    assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_sgv) <= LL_RTOL * abs(ll_sgv)
+
+
 def test_sgv_posterior_pass_wide_levels():
     # n large enough that the early levels of the schedule hold > 2048 columns (one wave per column) next to the
     # 8- and 16-wave narrow levels and the leaf level: the device posterior pass against the sparse host
