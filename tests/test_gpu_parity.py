@@ -411,6 +411,29 @@ def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
     assert abs(ll2 - G.vecchia_likelihood_U(z, U_obj)) <= 1e-9 * abs(ll2)
 
 
+@pytest.mark.parametrize("covmodel,cp", [("matern", [1.3, 0.2, 0.5]), ("matern", [1.3, 0.2, 1.5]), ("matern", [0.7, 0.2, 2.5]),
+                                         ("matern", [1.1, 0.2, 1.1]), ("esqe", [0.9, 0.3, 0.4, 0.2])])
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_coincident_locations_give_sigma2_exactly(covmodel, cp, d):
+    # dist == 0 -> sigma^2 exactly (src/Matern.cpp:35,48,63,76; src/Esqe.cpp:30-31): every third point is an exact
+    # duplicate of an earlier one (as with cond.yz = 'zy', R/vecchia_specify.R:195-196); observed-conditioned blocks stay PD
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(11 + d)
+    n, m = 600, 14
+    locs = rng.random((n, d))
+    dup = np.arange(2, n, 3)
+    locs[dup] = locs[dup - 2]
+    va = R.vecchia_specify(locs, m, ordering="none", cond_yz="z")
+    tau = 0.2
+    ref = R.createU(va, cp, tau, covmodel)["U_entries"]
+    prep = va["U_prep"]
+    out = G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], np.full(n, tau), np.full(n, tau),
+                        covmodel, cp)
+    assert out["n_failed"] == ref["n_failed"] == 0
+    assert _row_err(out["Lentries"], ref["Lentries"]) < 1e-11
+
+
 def test_ic0_option_of_U2V():
     # vecchia_specify(..., ic0 = TRUE): U2V uses the zero-fill factor of W.rev (R/vecchia_prediction.R:76-77).
     # cond.yz = 'y' has fill, so the likelihood changes and must match the restatement of src/ic0.cpp; SGV has none.
