@@ -123,6 +123,11 @@ struct gpv_plan {
     double *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
+    // the posterior pass as a captured HIP graph (one per {denominator, denominator + mean}): ~140 (280) launches of a few
+    // microseconds each, which the host cannot enqueue as fast as the device retires them in the narrow tail levels
+    struct PostGraph { hipGraphExec_t exec = nullptr; double *sums_out = nullptr; };
+    PostGraph pgraph[2];
+    double *d_nug_post = nullptr;                    // [Nlocs] nuggets in ordering: fixed kernel argument for the graph
     int32_t *d_order2 = nullptr;
     double *d_u = nullptr, *d_mu = nullptr;
     bool have_mean = false;
@@ -176,7 +181,9 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp};
+                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post};
+    for (auto &g : pl->pgraph)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
@@ -418,24 +425,61 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
     if (flags & GPV_WANT_DENOM) {
+        // nuggets as a vector at a fixed address (scalar: broadcast), so that the pass's kernel arguments never change
+        if (pl->nug_is_scalar) GPV_HIP(launch_fill(pl->d_nug_post, pl->nug_scalar, pl->Nlocs, st));
+        else GPV_HIP(hipMemcpyAsync(pl->d_nug_post, pl->d_nug_user, sizeof(double) * (size_t)pl->Nlocs,
+                                    hipMemcpyDeviceToDevice, st));
         PostArgs pa;
         pa.colptr = pl->d_colptr; pa.crow = pl->d_crow;
         pa.colrec = pl->d_colrec; pa.rowrec = pl->d_rowrec; pa.tp = pl->d_tp;
         pa.C = pl->d_C; pa.z = pl->d_zuser;
-        pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
-        pa.nug_scalar = pl->nug_scalar;
+        pa.nuggets = pl->d_nug_post;
+        pa.nug_scalar = 0.0;
         pa.tvec = pl->d_tvec; pa.logr = pl->d_logr; pa.ld = pl->P;
-        GPV_HIP(launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot, pl->Nlocs,
-                                         pl->post_nnz, pl->d_C, st));
-        for (size_t lv = 0; lv + 1 < pl->levptr.size(); ++lv)
-            GPV_HIP(launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st));
-        GPV_HIP(launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st));
-        if (flags & GPV_WANT_MEAN) {
-            for (size_t lv = 0; lv + 1 < pl->levptr2.size(); ++lv)
-                GPV_HIP(launch_mean_level(pa, pl->d_order2, pl->d_u, pl->levptr2[lv], pl->levptr2[lv + 1] - pl->levptr2[lv], st));
-            GPV_HIP(launch_negate(pl->d_u, pl->d_mu, pl->Nlocs, st));
-            pl->have_mean = true;
+        const bool want_mean = (flags & GPV_WANT_MEAN) != 0;
+        auto enqueue = [&]() -> hipError_t {
+            hipError_t e = launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot,
+                                                    pl->Nlocs, pl->post_nnz, pl->d_C, st);
+            for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr.size(); ++lv)
+                e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st);
+            if (e == hipSuccess)
+                e = launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st);
+            if (want_mean) {
+                for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr2.size(); ++lv)
+                    e = launch_mean_level(pa, pl->d_order2, pl->d_u, pl->levptr2[lv],
+                                          pl->levptr2[lv + 1] - pl->levptr2[lv], st);
+                if (e == hipSuccess) e = launch_negate(pl->d_u, pl->d_mu, pl->Nlocs, st);
+            }
+            return e;
+        };
+        gpv_plan::PostGraph &g = pl->pgraph[want_mean ? 1 : 0];
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        static const bool no_graph = getenv("GPV_NO_GRAPH") != nullptr;
+        bool launched = false;
+        if (!no_graph && cap == hipStreamCaptureStatusNone) {
+            if (!g.exec || g.sums_out != d_sums_out) {                     // first use, or another mirror address
+                if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+                if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const hipError_t e = enqueue();
+                    hipGraph_t graph = nullptr;
+                    const hipError_t e2 = hipStreamEndCapture(st, &graph);
+                    if (e == hipSuccess && e2 == hipSuccess && graph &&
+                        hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess)
+                        g.sums_out = d_sums_out;
+                    else
+                        g.exec = nullptr;
+                    if (graph) (void)hipGraphDestroy(graph);
+                    (void)hipGetLastError();
+                }
+            }
+            if (g.exec) {
+                GPV_HIP(hipGraphLaunch(g.exec, st));
+                launched = true;
+            }
         }
+        if (!launched) GPV_HIP(enqueue());                               // inside someone else's capture, or graphs off
+        if (want_mean) pl->have_mean = true;
     }
     pl->evaluated = true;
     pl->have_U = (flags & GPV_WANT_U) != 0;
@@ -631,6 +675,9 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     const size_t nd = sizeof(double) * (size_t)n;
     if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
+    if (!pl->d_nug_post) GPV_HIP(hipMalloc((void **)&pl->d_nug_post, nd));
+    for (auto &g : pl->pgraph)                                         // the schedule may have changed
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (!pl->d_tvec) GPV_HIP(hipMalloc((void **)&pl->d_tvec, nd));
     if (!pl->d_logr) GPV_HIP(hipMalloc((void **)&pl->d_logr, nd));
     if (!pl->d_u) GPV_HIP(hipMalloc((void **)&pl->d_u, nd));
