@@ -122,8 +122,10 @@ NA_INTEGER = -2147483648
 def as_r_int_matrix(a):
     """float/int matrix with NaN (R's NA) -> Fortran-ordered int32 with NA_INTEGER."""
     a = np.asarray(a)
+    if a.dtype == np.int32 and a.flags.f_contiguous:
+        return a                                                 # already what R's .C() would pass
     if a.dtype.kind == "f":
-        out = np.where(np.isnan(a), NA_INTEGER, a).astype(np.int32)
+        out = np.where(np.isnan(a), NA_INTEGER, a)
     else:
-        out = a.astype(np.int32)
-    return np.asfortranarray(out)
+        out = a
+    return np.asarray(out, dtype=np.int32, order="F")            # one pass: cast and transpose together

