@@ -1130,6 +1130,20 @@ int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t fir
     CD(0, 0) = 1;                                                        // :10
     for (int c = 0; c < p; ++c) has_na[0] |= (NN(0, c) == 0);
     for (int64_t k = 1; k < n; ++k) {                                    // :12
+        // the loop is bound by the ~2p random row reads per point: fetch the rows point k+2 will look at now
+        if (k + 2 < n) {
+            for (int c = 1; c < p; ++c) {
+                const int64_t l = NN(k + 2, c);
+                if (l != 0) {
+                    const char *a = reinterpret_cast<const char *>(&nnr[(size_t)(l - 1) * p]);
+                    const char *b = reinterpret_cast<const char *>(&cdr[(size_t)(l - 1) * p]);
+                    for (int off = 0; off < p * 4; off += 64) {
+                        __builtin_prefetch(a + off);
+                        __builtin_prefetch(b + off);
+                    }
+                }
+            }
+        }
         int n_na = 0;
         for (int c = 0; c < p; ++c) {
             const int64_t v = NN(k, c);
