@@ -489,6 +489,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.cov = cs.cov;
     a.flags = flags;
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
+    if (cs.cov == COV_MATERN_GEN) bessel_tab_fill(cs.sB, a.bt);
+    else std::memset(&a.bt, 0, sizeof(a.bt));
     GPV_HIP(hipEventRecord(pl->ev0, st));
     GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone

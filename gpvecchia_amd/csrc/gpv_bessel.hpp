@@ -11,10 +11,11 @@
 // [0, 1/4] computed with 60-digit arithmetic, max abs error 2.5e-22 / 2.9e-21).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
 
 namespace gpv {
 
-__device__ __forceinline__ void temme_gammas(double mu, double &gam1, double &gam2, double &gampl, double &gammi)
+__host__ __device__ __forceinline__ void temme_gammas(double mu, double &gam1, double &gam2, double &gampl, double &gammi)
 {
     const double t = mu * mu;
     double g1 = 0x1.42325eabf5d31p-30;
@@ -114,6 +115,128 @@ __device__ inline double bessel_k_nu(double nu, double x)
         rk1 = rktemp;
     }
     return rkmu;
+}
+
+// ---- the same with everything that depends on nu alone taken out of the per-pair work ---------------------------
+// Inside one launch nu is fixed, so the order-dependent constants of Temme's series and the reciprocals its
+// recurrences divide by (1/(i^2 - mu^2), 1/(i - mu), 1/(i + mu), 1/i) are computed once on the host and travel in the
+// kernel arguments: the series index is wave-uniform, so they are scalar loads and the four divisions per term become
+// multiplications.  x^nu reuses the logarithm the series needs, and cosh/sinh come from one exp.
+struct BesselTab {
+    static constexpr int N = 24;       // series terms covered by the tables (x <= 2 needs <= ~19 for 1e-17)
+    double r[4][N];
+    double c[8];                       // fact, gam1, gam2, 0.5/Gamma(1+mu)^-1.., see bessel_tab_fill
+};
+
+inline void bessel_tab_fill(double nu, BesselTab &t)
+{
+    const int nl = (int)(nu + 0.5);
+    const double mu = nu - (double)nl, mu2 = mu * mu;
+    const double pimu = 3.14159265358979323846 * mu;
+    double gam1, gam2, gampl, gammi;
+    temme_gammas(mu, gam1, gam2, gampl, gammi);
+    t.c[0] = (fabs(pimu) < 1e-15) ? 1.0 : pimu / sin(pimu);
+    t.c[1] = gam1;
+    t.c[2] = gam2;
+    t.c[3] = 0.5 / gampl;
+    t.c[4] = 0.5 / gammi;
+    t.c[5] = mu;
+    t.c[6] = mu2;
+    t.c[7] = (double)nl;
+    for (int i = 1; i <= BesselTab::N; ++i) {
+        const double di = (double)i;
+        t.r[0][i - 1] = 1.0 / (di * di - mu2);
+        t.r[1][i - 1] = 1.0 / (di - mu);
+        t.r[2][i - 1] = 1.0 / (di + mu);
+        t.r[3][i - 1] = 1.0 / di;
+    }
+}
+
+// K_nu(x) with lx = log(x) supplied by the caller
+__device__ inline double bessel_k_nu_tab(const BesselTab &T, double x, double lx)
+{
+    const double mu = T.c[5], mu2 = T.c[6];
+    const int nl = (int)T.c[7];
+    const double xi2 = 2.0 / x;
+    double rkmu, rk1;
+    if (x <= 2.0) {
+        const double x2 = 0.5 * x;
+        const double d = 0.693147180559945309417 - lx;          // -log(x/2)
+        const double e = mu * d;
+        const double ex = exp(e), iex = 1.0 / ex;
+        const double ch = 0.5 * (ex + iex);
+        const double e2 = e * e;
+        // sinh(e)/e: series below 0.1 (next term e^10/39916800 < 3e-18), else from the exponentials
+        const double shs = __builtin_fma(e2, __builtin_fma(e2, __builtin_fma(e2, __builtin_fma(e2, 1.0 / 362880.0, 1.0 / 5040.0),
+                                                                            1.0 / 120.0), 1.0 / 6.0), 1.0);
+        const double fact2 = (fabs(e) < 0.1) ? shs : 0.5 * (ex - iex) / e;
+        double ff = T.c[0] * (T.c[1] * ch + T.c[2] * fact2 * d);
+        double sum = ff;
+        double p = T.c[3] * ex;
+        double q = T.c[4] * iex;
+        double c = 1.0;
+        const double dd = x2 * x2;
+        double sum1 = p;
+        for (int i = 1; i <= 1000; ++i) {
+            const double di = (double)i;
+            double r0, r1, r2, r3;
+            if (i <= BesselTab::N) {
+                r0 = T.r[0][i - 1]; r1 = T.r[1][i - 1]; r2 = T.r[2][i - 1]; r3 = T.r[3][i - 1];
+            } else {
+                r0 = 1.0 / (di * di - mu2); r1 = 1.0 / (di - mu); r2 = 1.0 / (di + mu); r3 = 1.0 / di;
+            }
+            ff = (di * ff + p + q) * r0;
+            c *= dd * r3;
+            p *= r1;
+            q *= r2;
+            const double del = c * ff;
+            sum += del;
+            sum1 += c * (p - di * ff);
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        rkmu = sum;
+        rk1 = sum1 * xi2;
+    } else {
+        // Steed's algorithm for CF2 (as in bessel_k_nu)
+        double b = 2.0 * (1.0 + x);
+        double d = 1.0 / b;
+        double h = d, delh = d;
+        double q1 = 0.0, q2 = 1.0;
+        const double a1 = 0.25 - mu2;
+        double q = a1, c = a1;
+        double a = -a1;
+        double s = 1.0 + q * delh;
+        for (int i = 2; i <= 10000; ++i) {
+            a -= 2.0 * (double)(i - 1);
+            c = -a * c / (double)i;
+            const double qnew = (q1 - b * q2) / a;
+            q1 = q2;
+            q2 = qnew;
+            q += c * qnew;
+            b += 2.0;
+            d = 1.0 / (b + a * d);
+            delh = (b * d - 1.0) * delh;
+            h += delh;
+            const double dels = q * delh;
+            s += dels;
+            if (fabs(dels) < fabs(s) * 1e-17) break;
+        }
+        h = a1 * h;
+        rkmu = sqrt(3.14159265358979323846 / (2.0 * x)) * exp(-x) / s;
+        rk1 = rkmu * (mu + x + 0.5 - h) / x;
+    }
+    for (int i = 1; i <= nl; ++i) {
+        const double rktemp = (mu + (double)i) * xi2 * rk1 + rkmu;
+        rkmu = rk1;
+        rk1 = rktemp;
+    }
+    return rkmu;
+}
+
+__device__ inline double matern_general_tab(const BesselTab &T, double s, double normcon, double nu)
+{
+    const double ls = log(s);
+    return normcon * exp(nu * ls) * bessel_k_nu_tab(T, s, ls);
 }
 
 // sigma^2 2^{1-nu}/Gamma(nu) s^nu K_nu(s), s = dist/range  (src/Matern.cpp:73,80; no sqrt(2 nu) scaling there)

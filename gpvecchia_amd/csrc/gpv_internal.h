@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gpv_bessel.hpp"
 
 namespace gpv {
 
@@ -39,6 +40,7 @@ struct SetArgs {
     //   esqe:   sig0 = s1+s2, sA = s1, cA = 1/r1, sB = s2, cB = 1/r2^2
     double sig0, sA, cA, sB, cB;
     double nug_scalar;       // constant nugget (R/createU.R:74) when nuggets == nullptr
+    BesselTab bt;            // COV_MATERN_GEN: order-dependent constants of K_nu (gpv_bessel.hpp), filled on the host
 };
 
 // launch the conditioning-set kernel compiled for row length P (one of gpv_plist.h); the grid is chosen from

@@ -199,7 +199,8 @@ __device__ __forceinline__ double exp_neg(double t)
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
 // (src/Matern.cpp:35,48,63; src/Esqe.cpp:30-31)
 template <int COV>
-__device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA, double cA, double sB, double cB)
+__device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA, double cA, double sB, double cB,
+                                              const BesselTab &bt)
 {
     const double dist = sqrt_pos(r2);
     double v;
@@ -213,7 +214,7 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
         const double t = dist * cA;                 // sqrt(5) * dist / range
         v = sA * exp_neg(t) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);   // src/Matern.cpp:68
     } else if constexpr (COV == COV_MATERN_GEN) {
-        v = (r2 == 0.0) ? sig0 : matern_general(dist * cA, sA, sB);                      // src/Matern.cpp:72-84
+        v = (r2 == 0.0) ? sig0 : matern_general_tab(bt, dist * cA, sA, sB);              // src/Matern.cpp:72-84
     } else {
         v = __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));                // src/Esqe.cpp:33-35
     }
@@ -224,9 +225,10 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // is clamped at the smallest normal number instead, where every closed form returns sigma^2 exactly
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
 template <int COV>
-__device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB)
+__device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
+                                             const BesselTab &bt)
 {
-    if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
+    if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, bt);
     r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
     const double dist = sqrt_pos(r2);
     if constexpr (COV == COV_MATERN15) {
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                                 r2 = __builtin_fma(df, df, r2);
                             }
                         }
-                        v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB);
+                        v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A.bt);
                         if constexpr (MASKED) {                  // padded rows/cols -> identity
                             bool jvalid = false;
 #pragma unroll
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV>(r2, sig0, sA, cA, sB, cB);
+                    v[q] = cov_closed<COV>(r2, sig0, sA, cA, sB, cB, A.bt);
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;
