@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <mutex>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -180,6 +181,10 @@ struct gpv_plan {
     struct PostGraph { hipGraphExec_t exec = nullptr; double *sums_out = nullptr; };
     PostGraph pgraph[2];
     double *d_nug_post = nullptr;                    // [Nlocs] nuggets in ordering: fixed kernel argument for the graph
+    // general-nu Matern: range of pair distances of the plan (parameter independent) and the per-evaluation table
+    double dist_min = 0.0, dist_max = 0.0;
+    double *d_mt = nullptr;
+    std::vector<double> h_mt;
     int32_t *d_order2 = nullptr;
     double *d_u = nullptr, *d_mu = nullptr;
     bool have_mean = false;
@@ -233,7 +238,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post};
+                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -392,6 +397,36 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
         });
     }
 
+    // range of the pair distances inside conditioning sets (for the general-nu table): the closest pair overall is some
+    // point and its nearest earlier neighbour; no pair of a set is farther apart than twice its farthest neighbour
+    if (locs) {
+        std::mutex mu_;
+        double gmin = INFINITY, gmax = 0.0;
+        parallel_for(Nlocs, [&](int64_t b, int64_t e) {
+            double lmin = INFINITY, lmax = 0.0;
+            for (int64_t k = b; k < e; ++k) {
+                const int self = revNN[k + (int64_t)(ncolNN - 1) * Nlocs];
+                if (is_missing(self) || self < 1 || (int64_t)self > Nlocs) continue;
+                for (int j = 0; j < ncolNN - 1; ++j) {
+                    const int v = revNN[k + (int64_t)j * Nlocs];
+                    if (is_missing(v) || v < 1 || (int64_t)v > Nlocs) continue;
+                    double r2 = 0.0;
+                    for (int t = 0; t < dim; ++t) {
+                        const double df = locs[(self - 1) + (int64_t)t * Nlocs] - locs[(v - 1) + (int64_t)t * Nlocs];
+                        r2 += df * df;
+                    }
+                    const double dd = std::sqrt(r2);
+                    if (dd > lmax) lmax = dd;                    // first valid entry is the farthest, but rows need not be sorted
+                    if (dd > 0.0 && dd < lmin) lmin = dd;
+                }
+            }
+            std::lock_guard<std::mutex> g(mu_);
+            if (lmin < gmin) gmin = lmin;
+            if (lmax > gmax) gmax = lmax;
+        });
+        pl->dist_min = std::isfinite(gmin) ? gmin : 0.0;
+        pl->dist_max = gmax;
+    }
     tm.lap("plan: location records");
     auto fail = [&](int code) {
         gpv_plan_destroy(pl);
@@ -489,8 +524,26 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.cov = cs.cov;
     a.flags = flags;
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
-    if (cs.cov == COV_MATERN_GEN) bessel_tab_fill(cs.sB, a.bt);
-    else std::memset(&a.bt, 0, sizeof(a.bt));
+    a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0;
+    if (cs.cov == COV_MATERN_GEN) {
+        bessel_tab_fill(cs.sB, a.bt);
+        static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
+        if (!no_tab && pl->dist_min > 0.0 && pl->dist_max >= pl->dist_min) {
+            constexpr int kMaxSeg = 320;                                   // 80 octaves
+            if (!pl->d_mt) GPV_HIP(hipMalloc((void **)&pl->d_mt, sizeof(double) * kMaxSeg * MaternTab::ROW));
+            pl->h_mt.resize((size_t)kMaxSeg * MaternTab::ROW);
+            GPV_HIP(hipStreamSynchronize(st));                             // the previous upload has left h_mt
+            matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, pl->h_mt.data(), &a.mt_base,
+                             &a.mt_nseg, kMaxSeg);
+            if (a.mt_nseg > 0) {
+                GPV_HIP(hipMemcpyAsync(pl->d_mt, pl->h_mt.data(), sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
+                                       hipMemcpyHostToDevice, st));
+                a.mt = pl->d_mt;
+            }
+        }
+    } else {
+        std::memset(&a.bt, 0, sizeof(a.bt));
+    }
     GPV_HIP(hipEventRecord(pl->ev0, st));
     GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone

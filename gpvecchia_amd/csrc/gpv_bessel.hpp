@@ -42,7 +42,7 @@ __host__ __device__ __forceinline__ void temme_gammas(double mu, double &gam1, d
     gammi = g2 + mu * g1;      // 1 / Gamma(1 - mu)
 }
 
-__device__ inline double bessel_k_nu(double nu, double x)
+__host__ __device__ inline double bessel_k_nu(double nu, double x)
 {
     const int nl = (int)(nu + 0.5);
     const double mu = nu - (double)nl;
@@ -237,6 +237,51 @@ __device__ inline double matern_general_tab(const BesselTab &T, double s, double
 {
     const double ls = log(s);
     return normcon * exp(nu * ls) * bessel_k_nu_tab(T, s, ls);
+}
+
+// ---- per-launch table of h(s) = s^nu K_nu(s) e^s ------------------------------------------------------------------
+// nu is fixed inside a launch and h is smooth and slowly varying away from s = 0, so the host fits it once per
+// evaluation on the segments [2^e (1 + m/4), 2^e (1 + (m+1)/4)), m = 0..3 (segment index = the exponent and the two
+// leading mantissa bits of s: one shift), degree 12 in the Chebyshev basis: the nearest singularity (s = 0) is at least
+// 9 half-widths from a segment's centre, so the truncation error is below 18^-13 ~ 5e-17 relative.  One segment is one
+// 128-byte row {centre, 1/half-width, a_0 .. a_12, 0}.  The device evaluates h by Clenshaw's recurrence and multiplies by
+// exp(-s); distances outside the tabulated range take the series / continued-fraction path above.
+struct MaternTab {
+    static constexpr int DEG = 12, ROW = 16;
+};
+
+inline void matern_tab_build(double nu, double smin, double smax, double *rows /* nseg x 16 */, int *base_idx, int *nseg,
+                             int max_seg)
+{
+    constexpr int N = MaternTab::DEG + 1;
+    int e_lo = (int)std::floor(std::log2(smin)), e_hi = (int)std::floor(std::log2(smax));
+    if (e_lo < -200) e_lo = -200;
+    if (e_hi > 8) e_hi = 8;                                   // s < 512: K_nu(s) e^s stays in range; beyond, the value is ~0 anyway
+    if (e_hi < e_lo) { *nseg = 0; *base_idx = 0; return; }
+    if ((e_hi - e_lo + 1) * 4 > max_seg) e_lo = e_hi + 1 - max_seg / 4;
+    *base_idx = (e_lo + 1023) << 2;
+    *nseg = (e_hi - e_lo + 1) * 4;
+    double cs[N][N];
+    for (int k = 0; k < N; ++k)
+        for (int j = 0; j < N; ++j) cs[k][j] = std::cos(3.14159265358979323846 * k * (j + 0.5) / N);
+    for (int seg = 0; seg < *nseg; ++seg) {
+        const int e = e_lo + seg / 4, m = seg % 4;
+        const double c = std::ldexp(1.0 + (m + 0.5) / 4.0, e), hw = std::ldexp(1.0, e - 3);
+        double f[N];
+        for (int j = 0; j < N; ++j) {
+            const double s = c + hw * cs[1][j];
+            f[j] = std::exp(nu * std::log(s) + s) * bessel_k_nu(nu, s);
+        }
+        double *row = rows + (size_t)seg * MaternTab::ROW;
+        row[0] = c;
+        row[1] = 1.0 / hw;
+        for (int k = 0; k < N; ++k) {
+            double a = 0.0;
+            for (int j = 0; j < N; ++j) a += f[j] * cs[k][j];
+            row[2 + k] = a * (k == 0 ? 1.0 : 2.0) / N;
+        }
+        row[15] = 0.0;
+    }
 }
 
 // sigma^2 2^{1-nu}/Gamma(nu) s^nu K_nu(s), s = dist/range  (src/Matern.cpp:73,80; no sqrt(2 nu) scaling there)

@@ -196,11 +196,39 @@ __device__ __forceinline__ double exp_neg(double t)
     return __builtin_ldexp(p, (int)kd);
 }
 
+// general-nu Matern through the per-launch table (gpv_bessel.hpp, MaternTab); outside its range the series path
+__device__ __forceinline__ double matern_general_seg(const double *mt, int mt_base, int mt_nseg, const BesselTab &bt,
+                                                     double s, double normcon, double nu)
+{
+    const int seg = (int)(__double_as_longlong(s) >> 50) - mt_base;
+    if ((unsigned)seg < (unsigned)mt_nseg) {
+        const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
+        const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6], q7 = row[7];
+        const double u = (s - q0.x) * q0.y, u2 = u + u;
+        // Clenshaw: b_k = a_k + 2u b_{k+1} - b_{k+2}; p = a_0 + u b_1 - b_2    (a_0 = q1.x ... a_12 = q7.x)
+        double b2 = 0.0, b1 = q7.x, b0;
+        b0 = __builtin_fma(u2, b1, q6.y) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q6.x) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q5.y) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q5.x) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q4.y) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q4.x) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q3.y) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q3.x) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q2.y) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q2.x) - b2; b2 = b1; b1 = b0;
+        b0 = __builtin_fma(u2, b1, q1.y) - b2; b2 = b1; b1 = b0;
+        const double p = __builtin_fma(u, b1, q1.x) - b2;
+        return normcon * p * exp_neg(s);
+    }
+    return matern_general_tab(bt, s, normcon, nu);
+}
+
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
 // (src/Matern.cpp:35,48,63; src/Esqe.cpp:30-31)
 template <int COV>
 __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA, double cA, double sB, double cB,
-                                              const BesselTab &bt)
+                                              const SetArgs &A)
 {
     const double dist = sqrt_pos(r2);
     double v;
@@ -214,7 +242,7 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
         const double t = dist * cA;                 // sqrt(5) * dist / range
         v = sA * exp_neg(t) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);   // src/Matern.cpp:68
     } else if constexpr (COV == COV_MATERN_GEN) {
-        v = (r2 == 0.0) ? sig0 : matern_general_tab(bt, dist * cA, sA, sB);              // src/Matern.cpp:72-84
+        v = (r2 == 0.0) ? sig0 : matern_general_seg(A.mt, A.mt_base, A.mt_nseg, A.bt, dist * cA, sA, sB);   // src/Matern.cpp:72-84
     } else {
         v = __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));                // src/Esqe.cpp:33-35
     }
@@ -226,9 +254,9 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
 template <int COV>
 __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
-                                             const BesselTab &bt)
+                                             const SetArgs &A)
 {
-    if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, bt);
+    if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
     r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
     const double dist = sqrt_pos(r2);
     if constexpr (COV == COV_MATERN15) {
@@ -382,7 +410,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                                 r2 = __builtin_fma(df, df, r2);
                             }
                         }
-                        v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A.bt);
+                        v = cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
                         if constexpr (MASKED) {                  // padded rows/cols -> identity
                             bool jvalid = false;
 #pragma unroll
@@ -456,7 +484,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV>(r2, sig0, sA, cA, sB, cB, A.bt);
+                    v[q] = cov_closed<COV>(r2, sig0, sA, cA, sB, cB, A);
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;

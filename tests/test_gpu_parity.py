@@ -361,8 +361,11 @@ def test_general_nu_maternfun_vs_scipy_bessel(nu):
         assert np.all(np.abs(out[~ok]) < 1e-280)
 
 
-@pytest.mark.parametrize("nu", [0.8, 1.0, 2.2])
-@pytest.mark.parametrize("cond", ["z", "SGV"])
+# latent conditioning with a very smooth kernel is singular to working precision (cond > 1e16 at nu >= 4.7 here): the
+# large orders are compared on observed conditioning, where the nugget keeps the blocks well conditioned
+@pytest.mark.parametrize("nu,cond", [(0.1, "z"), (0.1, "SGV"), (0.31, "z"), (0.31, "SGV"), (0.8, "z"), (0.8, "SGV"),
+                                     (1.0, "z"), (1.0, "SGV"), (2.2, "z"), (2.2, "SGV"), (4.7, "z"), (11.0, "z"),
+                                     (29.5, "z")])
 def test_general_nu_through_the_hot_path(nu, cond):
     G = _need_gpu()
     from oracle import r_side as R
