@@ -43,14 +43,14 @@ def flops_per_set(p, d):
     return p ** 3 / 3.0 + p ** 2 + 0.5 * p * (p - 1) * (3 * d + 25)
 
 
-def build_workload(n, m, d, rank, world, seed=0, sgv=False):
+def build_workload(n, m, d, rank, world, seed=0, sgv=False, device=0):
     from gpvecchia_amd import specify as S
     rng = np.random.default_rng(seed)
     locs = rng.random((n, d))
     z = np.random.default_rng(seed + 1).standard_normal(n)
     a = (rank * n) // world
     b = ((rank + 1) * n) // world
-    NN = S.find_ordered_nn_gpu(locs, m, rows=(a, b), device=int(os.environ.get("LOCAL_RANK", "0")))   # this rank's rows only
+    NN = S.find_ordered_nn_gpu(locs, m, rows=(a, b), device=device)   # this rank's rows only
     revNN = NN[:, ::-1].copy()
     if sgv:
         revCond = S.whichCondOnLatent(NN)[:, ::-1].copy()   # cond.yz='SGV' (R/vecchia_specify.R:182-183)
@@ -124,10 +124,26 @@ def main():
             print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # developer hook (not the measured configuration): GPV_BENCH_BACKEND=gloo lets several ranks share one GPU so that
+    # the sharding / reduction logic of N > 1 can be exercised on a single-GPU box; the collective then runs on host copies
+    backend = os.environ.get("GPV_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun the collective path runs even at N = 1
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+
+    def all_reduce_(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     import gpvecchia_amd as G
 
@@ -143,7 +159,7 @@ def main():
     t_setup = time.time()
     if args.mode == "S" and world > 1:
         raise SystemExit("mode S (SGV posterior pass) does not shard: replicas only (DESIGN.md §6)")
-    locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, sgv=(args.mode == "S"))
+    locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, sgv=(args.mode == "S"), device=local_rank)
     plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
     plan.set_data(z)
     if args.mode == "S":
@@ -164,7 +180,7 @@ def main():
     def step():
         plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
         if use_dist:
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)       # the ONE collective: 64 bytes over xGMI
+            all_reduce_(sums, dist.ReduceOp.SUM)              # the ONE collective: 64 bytes over xGMI
         host = sums.cpu().numpy()                             # scalar on the host (implicit stream sync)
         return G.loglik_from_sums(host, n) if args.mode == "S" else G.loglik_z_from_sums(host, n)
 
@@ -187,10 +203,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        all_reduce_(te, dist.ReduceOp.MAX)
         elapsed = float(te.item())
         km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
+        all_reduce_(km, dist.ReduceOp.MAX)
         k_ms = float(km.item())
     else:
         k_ms = float(np.mean(kernel_ms))
