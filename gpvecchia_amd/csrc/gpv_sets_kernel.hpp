@@ -8,10 +8,10 @@
 // How (not a translation of the reference):
 //   * one wavefront handles SPW = floor(64/LPS) conditioning sets at once; a set is spread
 //     over LPS lanes and lane (sub, i) owns the rows i, i+LPS, .. (RPL rows per lane: 2 for
-//     P <= 32, 1 above) of the symmetric block in 2*RPL*P VGPRs.  Two rows per lane halve
+//     24 <= P <= 41, 1 otherwise) of the symmetric block in 2*RPL*P VGPRs.  Two rows per lane halve
 //     the LDS broadcast volume per FMA and the per-pivot overhead per set;
 //   * neighbour indices / cond flags are read as one contiguous segment per set,
-//     coordinates gathered with one 8*D-byte load per lane and staged in LDS;
+//     coordinates and datum gathered as one 32-byte record per neighbour and staged in LDS;
 //   * the P(P-1)/2 distinct covariances are evaluated once each with a circulant
 //     pairing (lane i takes partners i+1..i+P/2 mod P: all lanes busy every
 //     round), staged in a packed triangle in LDS, then read back as full rows;
@@ -365,7 +365,6 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         }
         // wave-uniform: does any set of this task have padding (missing neighbours / rows beyond the data)?
         int nvalid = 0;
-        unsigned long long rowmask_all = 0ull;
         bool all_valid = true;
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
