@@ -1164,12 +1164,13 @@ int gpv_mplan_get_Lentries(gpv_mplan *mp, double *Lentries)
 int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t firstind_pred, int *Cond)
 {
     // R/whichCondOnLatent.R:2-26, literal semantics (is.element(NA, x) is TRUE when x holds an NA; first maximum).
-    // O(n p^2) with a stamp array instead of R's O(n p^3) nested is.element calls.
-    if (!NNarray || !Cond || n <= 0 || ncolNN < 1) return GPV_ERR_BAD_ARG;
+    // O(n p^2) with a stamp array instead of R's O(n p^3) nested is.element calls.  The loop is bound by the random
+    // row reads (under maxmin ordering the neighbours of a point are scattered over the whole array), so every finished
+    // row is kept as a compact list of its latent-conditioned neighbours (one cache line instead of two full rows) and
+    // the lists point k+2 will look at are prefetched.
+    if (!NNarray || !Cond || n <= 0 || ncolNN < 1 || n >= ((int64_t)1 << 31)) return GPV_ERR_BAD_ARG;
     const int p = ncolNN;
-    // row-major working copies (the R layout is column-major: stride n between a row's entries)
-    std::vector<int32_t> nnr((size_t)n * p);
-    std::vector<int> cdr((size_t)n * p, INT_MIN);
+    std::vector<int32_t> nnr((size_t)n * p);               // row-major working copy (the R layout has stride n)
     for (int c = 0; c < p; ++c)
         for (int64_t r = 0; r < n; ++r) {
             const int v = NNarray[r + (int64_t)c * n];
@@ -1177,44 +1178,41 @@ int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t fir
             if (w < 0 || (int64_t)w > n) return GPV_ERR_INDEX;
             nnr[(size_t)r * p + c] = w;
         }
-    auto NN = [&](int64_t r, int c) -> int64_t { return nnr[(size_t)r * p + c]; };
-    auto CD = [&](int64_t r, int c) -> int & { return cdr[(size_t)r * p + c]; };
-    std::vector<int64_t> stamp((size_t)n + 1, -1);
+    auto NN = [&](int64_t r, int c) -> int32_t { return nnr[(size_t)r * p + c]; };
+    const int LS = p + 1;                                   // lat row: [count, entries...]
+    std::vector<int32_t> lat((size_t)n * LS, 0);
+    std::vector<int32_t> stamp((size_t)n + 1, -1);
     std::vector<char> has_na((size_t)n, 0);
-    std::vector<int> latents(p);
-    CD(0, 0) = 1;                                                        // :10
+    std::vector<int> latents(p), cdrow(p);
+    for (int c = 0; c < p; ++c) Cond[(int64_t)c * n] = INT_MIN;
+    Cond[0] = 1;                                                         // :10
     for (int c = 0; c < p; ++c) has_na[0] |= (NN(0, c) == 0);
+    if (NN(0, 0) != 0) { lat[0] = 1; lat[1] = NN(0, 0); }
     for (int64_t k = 1; k < n; ++k) {                                    // :12
-        // the loop is bound by the ~2p random row reads per point: fetch the rows point k+2 will look at now
         if (k + 2 < n) {
             for (int c = 1; c < p; ++c) {
-                const int64_t l = NN(k + 2, c);
+                const int32_t l = NN(k + 2, c);
                 if (l != 0) {
-                    const char *a = reinterpret_cast<const char *>(&nnr[(size_t)(l - 1) * p]);
-                    const char *b = reinterpret_cast<const char *>(&cdr[(size_t)(l - 1) * p]);
-                    for (int off = 0; off < p * 4; off += 64) {
-                        __builtin_prefetch(a + off);
-                        __builtin_prefetch(b + off);
-                    }
+                    const char *a = reinterpret_cast<const char *>(&lat[(size_t)(l - 1) * LS]);
+                    __builtin_prefetch(a);
+                    __builtin_prefetch(a + 64);
                 }
             }
         }
         int n_na = 0;
         for (int c = 0; c < p; ++c) {
-            const int64_t v = NN(k, c);
-            if (v == 0) ++n_na; else stamp[v] = k;
+            const int32_t v = NN(k, c);
+            if (v == 0) ++n_na; else stamp[v] = (int32_t)k;
         }
         has_na[k] = n_na > 0;
         latents[0] = 0;
         for (int ind = 1; ind < p; ++ind) {                              // :14-18
             latents[ind] = 0;
-            const int64_t l = NN(k, ind);
+            const int32_t l = NN(k, ind);
             if (l != 0 && l < firstind_pred) {
+                const int32_t *lr = &lat[(size_t)(l - 1) * LS];
                 int cnt = 0;
-                for (int c = 0; c < p; ++c) {
-                    const int64_t u = NN(l - 1, c);
-                    if (u != 0 && CD(l - 1, c) == 1 && stamp[u] == k) ++cnt;
-                }
+                for (int t = 1; t <= lr[0]; ++t) cnt += (stamp[lr[t]] == (int32_t)k);
                 if (has_na[l - 1]) cnt += n_na;
                 latents[ind] = cnt;
             }
@@ -1222,28 +1220,32 @@ int gpv_whichCondOnLatent(const int *NNarray, int64_t n, int ncolNN, int64_t fir
         int best = 0;
         for (int ind = 1; ind < p; ++ind)
             if (latents[ind] > latents[best]) best = ind;                // which(latents == max)[1]
-        const int64_t ref = NN(k, best);                                 // :19
-        // :20 — table = NNarray[ref,] * CondOnLatent[ref,]; for ref == k that row is still all NA
-        std::vector<int64_t> tab;
-        bool tab_na = true;
-        if (ref - 1 != k) {
-            tab_na = has_na[ref - 1];
-            for (int c = 0; c < p; ++c)
-                if (NN(ref - 1, c) != 0 && CD(ref - 1, c) == 1) tab.push_back(NN(ref - 1, c));
+        const int32_t ref = NN(k, best);                                 // :19
+        // :20 -- table = NNarray[ref,] * CondOnLatent[ref,]; for ref == k that row is still all NA
+        const int32_t *tab = nullptr;
+        int ntab = 0;
+        if (ref != 0 && ref - 1 != k) {
+            tab = &lat[(size_t)(ref - 1) * LS + 1];
+            ntab = lat[(size_t)(ref - 1) * LS];
         }
         for (int c = 0; c < p; ++c) {
-            const int64_t v = NN(k, c);
+            const int32_t v = NN(k, c);
+            cdrow[c] = INT_MIN;
             if (v == 0) continue;                                        // stays NA (:23)
             int val = 0;
-            for (int64_t t : tab) val |= (t == v);
+            for (int t = 0; t < ntab; ++t) val |= (tab[t] == v);
             if (v >= firstind_pred) val = 1;                             // :21
-            CD(k, c) = val;
+            cdrow[c] = val;
         }
-        (void)tab_na;
-        if (NN(k, 0) != 0) CD(k, 0) = 1;                                 // :22
+        if (NN(k, 0) != 0) cdrow[0] = 1;                                 // :22
+        int32_t *lw = &lat[(size_t)k * LS];
+        int w = 0;
+        for (int c = 0; c < p; ++c) {
+            Cond[k + (int64_t)c * n] = cdrow[c];
+            if (cdrow[c] == 1) lw[++w] = NN(k, c);
+        }
+        lw[0] = w;
     }
-    for (int c = 0; c < p; ++c)
-        for (int64_t r = 0; r < n; ++r) Cond[r + (int64_t)c * n] = cdr[(size_t)r * p + c];
     return GPV_OK;
 }
 
