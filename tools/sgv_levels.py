@@ -16,7 +16,7 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 last = max(i for i, r in enumerate(rows) if "gpv_sets_kernel" in r["Kernel_Name"])
 ev = rows[last:]
 t0 = int(ev[0]["Start_Timestamp"])
-lev = [r for r in ev if "posterior_level" in r["Kernel_Name"]]
+lev = [r for r in ev if "posterior_le" in r["Kernel_Name"]]          # level kernels and the leaf kernel of level 0
 print("eval span ms", (int(ev[-1]["End_Timestamp"]) - t0) / 1e6, "kernels", len(ev))
 tot = 0
 for i, r in enumerate(lev):
