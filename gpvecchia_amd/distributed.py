@@ -30,9 +30,16 @@ def allreduce_sums(local_sums, group=None):
     if isinstance(local_sums, np.ndarray):
         t = torch.from_numpy(np.ascontiguousarray(local_sums, dtype=np.float64).copy())
         if dist.get_backend(group) == "nccl":
-            t = t.cuda()
+            # pinned staging both ways and a wait on the current stream only: `tensor.cpu()` right after an RCCL
+            # collective costs ~0.2 ms (measured in bench.py), the collective itself ~0.01 ms at 64 bytes
+            d = t.pin_memory().cuda(non_blocking=True)
+            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
+            out = torch.empty_like(t).pin_memory()
+            out.copy_(d, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return out.numpy().copy()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t.cpu().numpy()
+        return t.numpy()
     dist.all_reduce(local_sums, op=dist.ReduceOp.SUM, group=group)
     return local_sums
 
