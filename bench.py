@@ -11,18 +11,24 @@ resident in HBM before the timed region, as in the reference where vecchia_speci
 runs once and vecchia_likelihood() once per optimiser step (R/vecchia_wrappers.R:55,72-78).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload: n=1e6 uniform 2-D points (numpy default_rng(0)),
-ordering='none', exact ordered 30-NN, cond.yz='z', Matern nu=1.5, covparms (1, 0.02, 1.5),
-nugget 0.1, z ~ default_rng(1).standard_normal.  Rows shard contiguously over ranks
-(strong scaling: the metric fixes n = 1e6).
+With N > 1 and no RANK in the environment the parent starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, before anything touches the
+GPU) and relays rank 0's JSON line; under torchrun (RANK set) it is one of the ranks.
+
+Workload (SURVEY.md §8d, config C3 = BASELINE.json configs[2]): n=1e6 uniform 2-D points
+(numpy default_rng(0)), ordering='none', exact ordered 30-NN, cond.yz='z', Matern nu=1.5,
+covparms (1, 0.02, 1.5), nugget 0.1, z ~ default_rng(1).standard_normal.  Rows shard contiguously
+over ranks (strong scaling: the metric fixes n = 1e6).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,8 +37,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# algorithmic bytes per conditioning set, mode L (fused likelihood):
-#   n0*(4 B index + 1 B cond flag) + 8*d coords + 8 nugget + 8 z  + 16 B of partial sums
+FP64_PEAK_TF = 78.6      # MI355X FP64 vector peak (256 CUs x 128 flop/clk x 2.4 GHz), SURVEY.md §8d
+HBM_PEAK_GBS = 8000.0    # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+# algorithmic bytes per conditioning set:
+#   n0*(4 B index + 1 B cond flag) + 8*d coords + 8 nugget + 8 z  + out (16 B of partial sums, or 8*n0 B of U entries)
 # flop model of SURVEY.md §8d: p^3/3 + p^2 + p(p-1)/2 * (3d + 25)
 def alg_bytes_per_set(p, d, mode):
     out = 8 * p if mode in ("U", "S") else 16
@@ -43,7 +53,15 @@ def flops_per_set(p, d):
     return p ** 3 / 3.0 + p ** 2 + 0.5 * p * (p - 1) * (3 * d + 25)
 
 
-def build_workload(n, m, d, rank, world, seed=0, sgv=False, device=0):
+CONFIGS = {   # BASELINE.json configs[] index, n, m, d, nu, range
+    "C2": (1, 100_000, 20, 2, 1.5, 0.05),
+    "C3": (2, 1_000_000, 30, 2, 1.5, 0.02),
+    "C4": (3, 1_000_000, 60, 3, 0.5, 0.05),
+}
+
+
+def build_workload(n, m, d, rank, world, seed=0, device=0):
+    """ordering='none', cond.yz='z': this rank's rows of the exact ordered-NN arrays (GPU brute force, bit-exact)."""
     from gpvecchia_amd import specify as S
     rng = np.random.default_rng(seed)
     locs = rng.random((n, d))
@@ -52,46 +70,80 @@ def build_workload(n, m, d, rank, world, seed=0, sgv=False, device=0):
     b = ((rank + 1) * n) // world
     NN = S.find_ordered_nn_gpu(locs, m, rows=(a, b), device=device)   # this rank's rows only
     revNN = NN[:, ::-1].copy()
-    if sgv:
-        revCond = S.whichCondOnLatent(NN)[:, ::-1].copy()   # cond.yz='SGV' (R/vecchia_specify.R:182-183)
-    else:
-        revCond = np.where(revNN != 0, 0, -1).astype(np.int8)  # cond.yz='z' (R/vecchia_specify.R:189-190)
-        revCond[:, -1] = 1
+    revCond = np.where(revNN != 0, 0, -1).astype(np.int8)  # cond.yz='z' (R/vecchia_specify.R:189-190)
+    revCond[:, -1] = 1
     return locs, z, revNN, revCond, a, b
 
 
-def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample):
-    """Time the oracle's C restatement of U_NZentries (OpenMP, all host cores) on a bounded
-    contiguous sample of the SAME conditioning sets; report extrapolated evals/s."""
+def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3):
+    """Time the oracle's C restatement of U_NZentries (OpenMP, all host cores) on the conditioning sets
+    [a, b) of the SAME workload (the whole data set when it fits the time budget)."""
     from oracle import r_side as R
     a, b = rows_sample
-    sub = revNN[a:b]
-    used = np.unique(sub[sub != 0]) - 1
-    remap = np.zeros(locs.shape[0] + 1, dtype=np.int64)
-    remap[used + 1] = np.arange(1, used.size + 1)
-    nn2 = remap[sub]
-    # pad the sample to a square problem the oracle signature expects (Nlocs rows): extra rows empty
-    Nl = max(used.size, sub.shape[0])
-    nnp = np.zeros((Nl, sub.shape[1]), dtype=np.int64)
-    nnp[: sub.shape[0]] = nn2
-    cdp = np.zeros((Nl, sub.shape[1]))
-    cdp[: sub.shape[0]] = np.where(revCond[a:b] < 0, 0, revCond[a:b])
-    lp = np.zeros((Nl, locs.shape[1]))
-    lp[: used.size] = locs[used]
+    n = locs.shape[0]
+    full = (a == 0 and b == n)
+    if full:
+        lp, nnp = locs, revNN
+        cdp = np.where(revCond < 0, 0, revCond).astype(np.float64)
+        Nl = n
+    else:
+        sub = revNN[a:b]
+        used = np.unique(sub[sub != 0]) - 1
+        remap = np.zeros(n + 1, dtype=np.int64)
+        remap[used + 1] = np.arange(1, used.size + 1)
+        Nl = max(used.size, sub.shape[0])
+        nnp = np.zeros((Nl, sub.shape[1]), dtype=np.int64)
+        nnp[: sub.shape[0]] = remap[sub]
+        cdp = np.zeros((Nl, sub.shape[1]))
+        cdp[: sub.shape[0]] = np.where(revCond[a:b] < 0, 0, revCond[a:b])
+        lp = np.zeros((Nl, locs.shape[1]))
+        lp[: used.size] = locs[used]
     nug = np.full(Nl, tau)
     cores = R.max_threads()
     times = []
-    for _ in range(3):
+    for _ in range(repeats):
         t0 = time.perf_counter()
         R.U_NZentries(cores, 1, lp, nnp, cdp, nug, nug[:1], "matern", covparms)
         times.append(time.perf_counter() - t0)
     t = float(np.median(times))
     sets_per_s = (b - a) / t
-    return dict(value=sets_per_s / locs.shape[0], unit="evals/s", cores=cores, kind="port",
-                sample=f"{b - a} of {locs.shape[0]} conditioning sets (rows {a}..{b - 1}, all with n0=m+1), "
-                       f"oracle/u_nzentries_oracle.c U_NZentries only, OpenMP schedule(static) on {cores} threads, "
-                       f"median of 3 = {t:.3f} s, extrapolated linearly to n",
-                sets_per_s=sets_per_s, seconds=t)
+    if full:
+        sample = (f"all {n} conditioning sets (no extrapolation), oracle/u_nzentries_oracle.c U_NZentries only, OpenMP "
+                  f"schedule(static) on {cores} threads, median of {repeats} = {t:.3f} s")
+    else:
+        sample = (f"{b - a} of {n} conditioning sets (rows {a}..{b - 1}, all with n0=m+1), oracle/u_nzentries_oracle.c "
+                  f"U_NZentries only, OpenMP schedule(static) on {cores} threads, median of {repeats} = {t:.3f} s, "
+                  f"EXTRAPOLATED linearly to n")
+    return dict(value=sets_per_s / n, unit="evals/s", cores=cores, kind="port", sample=sample,
+                extrapolated=not full, sets_per_s=sets_per_s, seconds=t,
+                note="own C restatement of src/U_NZentries.cpp:39-69 without Armadillo's per-iteration temporaries: "
+                     "FASTER than the real reference (BASELINE.md §2), which cannot be built on this box")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks as fresh processes.  Nothing in this process has touched
+    the GPU (torch.cuda.device_count() does not initialise it), and nothing is exec'ed."""
+    import torch
+    backend = os.environ.get("GPV_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < args.gpus:
+        print(f"[bench] --gpus {args.gpus} but only {ndev} GPU(s) visible: refusing to report a {args.gpus}-GPU number",
+              file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
@@ -99,19 +151,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--m", type=int, default=30)
-    ap.add_argument("--d", type=int, default=2)
+    ap.add_argument("--n", type=int, default=None)
+    ap.add_argument("--m", type=int, default=None)
+    ap.add_argument("--d", type=int, default=None)
     ap.add_argument("--mode", choices=["L", "U", "S"], default="L",
                     help="L: fused log-likelihood, cond.yz='z' (headline); U: also materialise the U entries in HBM; "
-                         "S: the reference's default cond.yz='SGV' with the posterior pass (U2V) on the GPU, 1 GPU only")
-    ap.add_argument("--config", choices=["C2", "C3", "C4"], default=None,
-                    help="BASELINE.json parity configs (SURVEY.md §8d): C2 n=1e5 m=20 d=2; C3 n=1e6 m=30 d=2 (the default, "
-                         "the configuration the metric is quoted on); C4 n=1e6 m=60 d=3 exponential")
-    ap.add_argument("--nu", type=float, default=1.5)
+                         "S: the reference's defaults, ordering='maxmin' + cond.yz='SGV', posterior pass (U2V) on the GPU, "
+                         "1 GPU only")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C3",
+                    help="BASELINE.json configs (SURVEY.md §8d): C2 n=1e5 m=20 d=2; C3 n=1e6 m=30 d=2 (default, the "
+                         "configuration the metric is quoted on); C4 n=1e6 m=60 d=3 exponential")
+    ap.add_argument("--nu", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=0, help="conditioning sets in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the mode U / mode S secondary measurements")
+    ap.add_argument("--cpu-budget-s", type=float, default=8.0,
+                    help="per-repeat wall budget of the CPU baseline; the whole data set is timed when it fits")
+    ap.add_argument("--self-check", action="store_true",
+                    help="N > 1: rank 0 also evaluates the unsharded plan and asserts the N-rank log-likelihood equals it to 1e-12")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
     import torch.distributed as dist
@@ -121,14 +183,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"[bench] note: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: launch with --nproc-per-node {args.gpus}", file=sys.stderr)
+        raise SystemExit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # developer hook (not the measured configuration): GPV_BENCH_BACKEND=gloo lets several ranks share one GPU so that
     # the sharding / reduction logic of N > 1 can be exercised on a single-GPU box; the collective then runs on host copies
     backend = os.environ.get("GPV_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and ndev < world:
+        raise SystemExit(f"[bench] {world} ranks but {ndev} GPU(s) visible")
     if backend != "nccl":
-        local_rank = local_rank % torch.cuda.device_count()
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or "RANK" in os.environ          # under torchrun the collective path runs even at N = 1
     if use_dist:
@@ -147,48 +213,28 @@ def main():
 
     import gpvecchia_amd as G
 
-    if args.config == "C2":
-        args.n, args.m, args.d, args.nu = 100_000, 20, 2, 1.5
-    elif args.config == "C4":
-        args.n, args.m, args.d, args.nu = 1_000_000, 60, 3, 0.5
-    n, m, d = args.n, args.m, args.d
+    ci, n, m, d, nu, rng_ = CONFIGS[args.config]
+    custom = any(v is not None for v in (args.n, args.m, args.d, args.nu))
+    n = args.n or n
+    m = args.m or m
+    d = args.d or d
+    nu = args.nu or nu
+    if args.d is not None:
+        rng_ = 0.02 if d == 2 else 0.05
     p = m + 1
-    rng_ = {("C2"): 0.05}.get(args.config, 0.02 if d == 2 else 0.05)
-    covparms = [1.0, rng_, args.nu]
+    covparms = [1.0, rng_, nu]
     tau = 0.1
-    t_setup = time.time()
     if args.mode == "S" and world > 1:
         raise SystemExit("mode S (SGV posterior pass) does not shard: replicas only (DESIGN.md §6)")
-    locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, sgv=(args.mode == "S"), device=local_rank)
-    plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
-    plan.set_data(z)
-    if args.mode == "S":
-        plan.build_posterior()
-    t_setup = time.time() - t_setup
 
-    flags = G.GPV_WANT_LOGLIK_Z | (G.GPV_WANT_U if args.mode == "U" else 0)
-    if args.mode == "S":
-        flags = G.GPV_WANT_DENOM
-    sums = torch.zeros(G._lib.NSUMS, dtype=torch.float64, device="cuda")
     # one explicit (non-null) HIP stream carries the kernel, the all-reduce and the D2H copy of every step;
     # a NULL handle would select the plan's private stream and un-order the consumers below
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
     assert stream != 0
-
+    sums = torch.zeros(G._lib.NSUMS, dtype=torch.float64, device="cuda")
     pinned = torch.zeros(G._lib.NSUMS, dtype=torch.float64).pin_memory()
-
-    def step():
-        plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
-        if use_dist:
-            all_reduce_(sums, dist.ReduceOp.SUM)              # the ONE collective: 64 bytes over xGMI
-        # the 8 sums reach the host every step through a pinned buffer: copy on the launch stream, then wait for that
-        # stream only (after an RCCL collective `sums.cpu()` costs 0.2 ms per step, as much as the kernel of one of 8 shards)
-        pinned.copy_(sums, non_blocking=True)
-        tstream.synchronize()
-        host = pinned.numpy()
-        return G.loglik_from_sums(host, n) if args.mode == "S" else G.loglik_z_from_sums(host, n)
 
     def fence():
         torch.cuda.synchronize()
@@ -196,69 +242,156 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    loglik = None
-    for _ in range(args.warmup):
-        loglik = step()
-    kernel_ms = []
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loglik = step()
-        kernel_ms.append(plan.last_kernel_ms())               # hipEvent pair on the launch stream, already complete
-    fence()
-    elapsed = time.perf_counter() - t0
+    def measure(plan, flags, denom, steps, warmup):
+        """W untimed + K timed evaluations of `plan`; returns (seconds, mean set-kernel ms, loglik)."""
+        def step():
+            plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
+            if use_dist:
+                all_reduce_(sums, dist.ReduceOp.SUM)              # the ONE collective: 64 bytes over xGMI
+            # the 8 sums reach the host every step through a pinned buffer: copy on the launch stream, then wait for
+            # that stream only
+            pinned.copy_(sums, non_blocking=True)
+            tstream.synchronize()
+            host = pinned.numpy()
+            return G.loglik_from_sums(host, n) if denom else G.loglik_z_from_sums(host, n)
+        ll = None
+        for _ in range(warmup):
+            ll = step()
+        kms = []
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ll = step()
+            kms.append(plan.last_kernel_ms())                    # hipEvent pair on the launch stream, already complete
+        fence()
+        el = time.perf_counter() - t0
+        return el, float(np.mean(kms)), ll
+
+    def roofline(k_ms, rows_rank, mode, traffic=None):
+        ab = alg_bytes_per_set(p, d, mode) * rows_rank
+        gbs = ab / (k_ms * 1e-3) / 1e9
+        tf = flops_per_set(p, d) * rows_rank / (k_ms * 1e-3) / 1e12
+        return {"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
+                "traffic": traffic, "kernel": f"gpv_sets_kernel<{p},{d}>", "kernel_ms": k_ms,
+                "flops_per_set": flops_per_set(p, d), "sets_per_launch": rows_rank,
+                "note": "binding roofline is FP64 VALU issue, not HBM or MFMA (blocks are (m+1)x(m+1); DESIGN.md §4); "
+                        "flop model of SURVEY.md §8d",
+                "hbm": {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "alg_bytes_per_set": alg_bytes_per_set(p, d, mode)}}
+
+    t_setup = time.time()
+    if args.mode == "S":
+        rng = np.random.default_rng(0)
+        locs = rng.random((n, d))
+        z = np.random.default_rng(1).standard_normal(n)
+        va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+        plan = G.Plan(va["locsord"], va["U_prep"]["revNNarray"], va["U_prep"]["revCond"], device=local_rank)
+        plan.set_data(z[va["ord_z"] - 1])
+        plan.build_posterior()
+        a, b = 0, n
+        flags, denom = G.GPV_WANT_DENOM, True
+    else:
+        locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, device=local_rank)
+        plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
+        plan.set_data(z)
+        flags, denom = G.GPV_WANT_LOGLIK_Z | (G.GPV_WANT_U if args.mode == "U" else 0), False
+    t_setup = time.time() - t_setup
+
+    elapsed, k_ms, loglik = measure(plan, flags, denom, args.steps, args.warmup)
     if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         all_reduce_(te, dist.ReduceOp.MAX)
         elapsed = float(te.item())
-        km = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
+        km = torch.tensor([k_ms], dtype=torch.float64, device="cuda")
         all_reduce_(km, dist.ReduceOp.MAX)
         k_ms = float(km.item())
-    else:
-        k_ms = float(np.mean(kernel_ms))
+
+    check = None
+    if args.self_check and world > 1 and rank == 0:
+        l1, z1, nn1, cd1, _, _ = build_workload(n, m, d, 0, 1, device=local_rank)
+        full = G.Plan(l1, nn1, cd1, device=local_rank)
+        full.set_data(z1)
+        full.eval("matern", covparms, tau, flags)
+        ll1 = G.loglik_z_from_sums(full.sums(), n)
+        del full
+        rel = abs(ll1 - loglik) / abs(ll1)
+        check = {"loglik_1rank": ll1, "loglik_nrank": loglik, "rel_diff": rel, "tol": 1e-12, "ok": bool(rel <= 1e-12)}
+        if not check["ok"]:
+            print(f"[bench] self-check FAILED: {check}", file=sys.stderr)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         rows_rank = b - a
-        ab = alg_bytes_per_set(p, d, args.mode) * rows_rank
-        achieved = ab / (k_ms * 1e-3) / 1e9
-        fl = flops_per_set(p, d) * rows_rank / (k_ms * 1e-3) / 1e12
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf) and n == 1_000_000 and m == 30 and d == 2 and world == 1 and args.mode == "L":
+        tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if os.path.exists(tf) and args.config == "C3" and not custom and world == 1 and args.mode == "L":
+            # HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh; quoted only while the kernel source
+            # they were measured on is the one in this tree
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                src = open(os.path.join(ROOT, "gpvecchia_amd", "csrc", "gpv_sets_kernel.hpp"), "rb").read()
+                if tj.get("kernel_source_sha256") == hashlib.sha256(src).hexdigest():
+                    traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        cond_s = "SGV" if args.mode == "S" else "z"
+        ord_s = "maxmin" if args.mode == "S" else "none"
         out = {
             "metric": "vecchia_loglik_evals_per_sec", "value": args.steps / elapsed, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"n={n} {d}-D uniform, Matern nu={args.nu}, m={m}, cond.yz={'SGV' if args.mode == 'S' else 'z'}, mode {args.mode} "
-                                   f"(BASELINE.json configs[2] geometry; rows sharded over {world} GPU(s))",
+            "config": {"workload": f"n={n} {d}-D uniform, Matern nu={nu}, m={m}, ordering={ord_s}, cond.yz={cond_s}, "
+                                   f"mode {args.mode} (" + ("custom sizes" if custom else f"BASELINE.json configs[{ci}]")
+                                   + f"; rows sharded over {world} GPU(s))",
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
                        "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "kernel": f"gpv_sets_kernel<{p},{d}>", "kernel_ms": k_ms,
-                         "alg_bytes_per_set": alg_bytes_per_set(p, d, args.mode),
-                         "fp64_valu": {"achieved": fl, "peak": 78.6, "unit": "TFLOP/s", "frac": fl / 78.6,
-                                       "flops_per_set": flops_per_set(p, d),
-                                       "note": "binding roofline: FP64 VALU issue, not HBM (DESIGN.md §4)"}},
+            "roofline": roofline(k_ms, rows_rank, args.mode, traffic),
         }
-        if not args.no_cpu_baseline:
-            sample = args.cpu_sample
-            if not sample:                      # calibrate: ~4 s of wall per repeat on all cores, 3 repeats
-                cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - 4000, b))
-                sample = int(min(b - a - 2 * p, max(20000, cal["sets_per_s"] * 4.0)))
-            lo = b - sample
-            out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (lo, b))
+        if check is not None:
+            out["self_check"] = check
+        if world == 1 and not args.no_secondary and args.mode == "L":
+            # secondary measurements of the same workload (same JSON line, not `value`):
+            #   mode U: the U entries materialised in HBM (the literal createU product, 8*(m+1) B per set written)
+            #   mode S: the reference's DEFAULTS, ordering='maxmin' + cond.yz='SGV', denominator (U2V) on the GPU
+            sec = {}
+            el, km, ll = measure(plan, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U, False, args.steps, 1)
+            sec["mode_U"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
+                             "kernel_ms": km, "loglik": ll,
+                             "hbm_alg_gbs": alg_bytes_per_set(p, d, "U") * n / (km * 1e-3) / 1e9,
+                             "what": "cond.yz='z', ordering='none', Lentries written to HBM"}
+            if p <= 64:
+                try:
+                    t0 = time.time()
+                    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+                    ps = G.Plan(va["locsord"], va["U_prep"]["revNNarray"], va["U_prep"]["revCond"], device=local_rank)
+                    ps.set_data(z[va["ord_z"] - 1])
+                    nlev = ps.build_posterior()
+                    ts = time.time() - t0
+                    el, km, ll = measure(ps, G.GPV_WANT_DENOM, True, args.steps, 2)
+                    sec["mode_S"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
+                                     "sets_kernel_ms": km, "loglik": ll, "levels": nlev, "setup_s": round(ts, 2),
+                                     "what": "the reference's defaults: ordering='maxmin', cond.yz='SGV'; set kernel + "
+                                             "posterior pass (U2V) on one GPU; does not shard"}
+                    del ps, va
+                except Exception as e:                       # never lose the headline line to a secondary failure
+                    sec["mode_S"] = {"error": repr(e)}
+            out["secondary"] = sec
+        if world == 1 and not args.no_cpu_baseline and args.mode != "S":
+            cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - 4000, b), repeats=2)
+            if n / cal["sets_per_s"] <= args.cpu_budget_s:
+                out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (0, n), repeats=3)
+            else:
+                sample = int(min(b - a - 2 * p, max(20000, cal["sets_per_s"] * args.cpu_budget_s)))
+                out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - sample, b), repeats=3)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
+    rc = 0 if (check is None or check["ok"]) else 3
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        raise SystemExit(rc)
 
 
 if __name__ == "__main__":

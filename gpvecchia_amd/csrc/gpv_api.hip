@@ -460,6 +460,8 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
 {
     if (!pl || !z_ord) return GPV_ERR_BAD_ARG;
     GPV_HIP(hipSetDevice(pl->device));
+    // an evaluation enqueued earlier on a caller stream may still be reading the records / d_zuser this call rewrites
+    if (pl->last_stream && pl->last_stream != pl->stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
     GPV_HIP(hipMemcpyAsync(pl->d_stage, z_ord, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyHostToDevice, pl->stream));
     if (pl->dim <= 3) {
         GPV_HIP(launch_scatter(pl->d_stage, pl->d_newpos, pl->Nlocs, pl->d_locs, 4, 3, pl->stream));   // rec[.][3] = datum
@@ -906,7 +908,9 @@ int gpv_loglik_z_from_sums(const double *s, int64_t n, double *loglik)
     if (!s || !loglik) return GPV_ERR_BAD_ARG;
     // -1/2 [ sum log(tau+v) + sum (z-mu)^2/(tau+v) + n log 2pi ]  == R/vecchia_likelihood.R:95-96 for cond.yz='z'
     if (s[6] > 0.0) {
-        *loglik = NAN;     // reference: zero rows in U => log(0) in logdet.num (R/vecchia_likelihood.R:76)
+        // a failed block leaves its Lentries row at zero (src/U_NZentries.cpp:64-66) => diag(U) = 0 => logdet.num = +Inf
+        // (R/vecchia_likelihood.R:76) => loglik = -Inf (:95-96); an optimiser comparing likelihoods sees "worst", not NaN
+        *loglik = -INFINITY;
         return GPV_OK;
     }
     *loglik = -0.5 * (s[2] + s[3] + (double)n * std::log(2.0 * M_PI));
@@ -918,7 +922,7 @@ int gpv_loglik_from_sums(const double *s, int64_t n, double *loglik)
     // R/vecchia_likelihood.R:95-96 with logdet.num = -2 s0 + s5, quadform.num = s1 + s4 (numerator sums) and, from the
     // posterior pass (GPV_WANT_DENOM), logdet.denom = -s2 (s2 = log det W), quadform.denom = s3
     if (!s || !loglik) return GPV_ERR_BAD_ARG;
-    if (s[6] > 0.0) { *loglik = NAN; return GPV_OK; }
+    if (s[6] > 0.0) { *loglik = -INFINITY; return GPV_OK; }      // as above: log(0) in logdet.num
     const double neg2 = (-2.0 * s[0] + s[5]) + s[2] + (s[1] + s[4]) - s[3] + (double)n * std::log(2.0 * M_PI);
     *loglik = -0.5 * neg2;
     return GPV_OK;

@@ -21,23 +21,18 @@ def shard_rows(n_rows: int, rank: int, world: int):
 
 
 def allreduce_sums(local_sums, group=None):
-    """Sum the per-rank partial sums.  `local_sums`: torch tensor (any device) or numpy array of
-    length NSUMS.  Returns the reduced values in the same kind of container."""
+    """Sum the per-rank partial sums.  `local_sums`: torch tensor (any device; with backend "nccl" it must live on this
+    rank's GPU) or numpy array of length NSUMS (host backends only: ShardedLikelihood keeps its own device buffer for
+    RCCL).  Returns the reduced values in the same kind of container."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return local_sums
     if isinstance(local_sums, np.ndarray):
-        t = torch.from_numpy(np.ascontiguousarray(local_sums, dtype=np.float64).copy())
         if dist.get_backend(group) == "nccl":
-            # pinned staging both ways and a wait on the current stream only: `tensor.cpu()` right after an RCCL
-            # collective costs ~0.2 ms (measured in bench.py), the collective itself ~0.01 ms at 64 bytes
-            d = t.pin_memory().cuda(non_blocking=True)
-            dist.all_reduce(d, op=dist.ReduceOp.SUM, group=group)
-            out = torch.empty_like(t).pin_memory()
-            out.copy_(d, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            return out.numpy().copy()
+            raise ValueError("allreduce_sums: pass a tensor on this rank's GPU with the nccl backend "
+                             "(ShardedLikelihood does; a host array has no device to reduce on)")
+        t = torch.from_numpy(np.ascontiguousarray(local_sums, dtype=np.float64).copy())
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return t.numpy()
     dist.all_reduce(local_sums, op=dist.ReduceOp.SUM, group=group)
@@ -48,9 +43,14 @@ class ShardedLikelihood:
     """vecchia_likelihood() for cond.yz='z' with the rows split over the ranks of a process group.
 
     plan_factory(row_begin, row_end) must return an object with set_data / eval / sums (api.Plan on a
-    GPU box; the CPU tests inject a stand-in that computes its shard's sums with the oracle)."""
+    GPU box; the CPU tests inject a stand-in that computes its shard's sums with the oracle).
 
-    def __init__(self, n_rows, z_ord, plan_factory, rank=None, world=None, group=None):
+    With the "nccl" (= RCCL) backend the rank is bound to ONE GPU: `device` (default: the plan's device, else
+    LOCAL_RANK).  The evaluation, the all-reduce of the 8 partial sums and their copy to a pinned host buffer are
+    enqueued on one private stream; the device buffer the kernel deposits its sums in is the buffer RCCL reduces
+    (no host round trip before the collective, no per-evaluation allocation)."""
+
+    def __init__(self, n_rows, z_ord, plan_factory, rank=None, world=None, group=None, device=None):
         import torch.distributed as dist
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -59,10 +59,35 @@ class ShardedLikelihood:
         self.rank, self.world, self.group = rank, world, group
         self.n = int(n_rows)
         self.row_begin, self.row_end = shard_rows(self.n, rank, world)
+        self._nccl = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        if self._nccl:
+            import os
+            import torch
+            if device is None:
+                device = int(os.environ.get("LOCAL_RANK", rank))
+            torch.cuda.set_device(device)                  # RCCL reduces on the CURRENT device of each rank
         self.plan = plan_factory(self.row_begin, self.row_end)
+        if self._nccl:
+            pdev = getattr(self.plan, "device", device)
+            if pdev != device:
+                raise ValueError(f"rank {rank}: plan lives on GPU {pdev} but the rank is bound to GPU {device}")
+            self.device = device
+            self._stream = torch.cuda.Stream(device=device)
+            self._d = torch.zeros(NSUMS, dtype=torch.float64, device=f"cuda:{device}")
+            self._h = torch.zeros(NSUMS, dtype=torch.float64).pin_memory()
         self.plan.set_data(z_ord)
 
     def sums(self, covmodel, covparms, nuggets, flags):
+        if self._nccl:
+            import torch
+            import torch.distributed as dist
+            with torch.cuda.stream(self._stream):
+                self.plan.eval(covmodel, covparms, nuggets, flags, stream=self._stream.cuda_stream,
+                               d_sums_out=self._d.data_ptr())
+                dist.all_reduce(self._d, op=dist.ReduceOp.SUM, group=self.group)   # the ONE collective: 64 bytes
+                self._h.copy_(self._d, non_blocking=True)
+            self._stream.synchronize()
+            return self._h.numpy().copy()
         self.plan.eval(covmodel, covparms, nuggets, flags)
         s = np.asarray(self.plan.sums(), dtype=np.float64)
         assert s.shape == (NSUMS,)
@@ -72,5 +97,5 @@ class ShardedLikelihood:
         from ._lib import GPV_WANT_LOGLIK_Z
         s = self.sums(covmodel, covparms, nuggets, GPV_WANT_LOGLIK_Z)
         if s[6] > 0:
-            return float("nan")
+            return float("-inf")              # failed block => zero row of U => logdet.num = +Inf (R/vecchia_likelihood.R:76)
         return float(-0.5 * (s[2] + s[3] + self.n * np.log(2.0 * np.pi)))

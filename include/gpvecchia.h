@@ -135,7 +135,9 @@ int gpv_plan_create(gpv_plan **plan, int device, int64_t Nlocs, int dim, int nco
 int gpv_plan_destroy(gpv_plan *plan);
 
 /* z in ORDERED observation order (zord of R/vecchia_likelihood.R:68), length Nlocs.
- * Log-likelihood sums assume every location is observed (obs all TRUE, no 'zy'). */
+ * Log-likelihood sums assume every location is observed (obs all TRUE, no 'zy').
+ * Blocking; it first waits for the stream of the plan's last evaluation, so an eval still in flight on a caller
+ * stream never sees half-written data. */
 int gpv_plan_set_data(gpv_plan *plan, const double *z_ord);
 
 /* One evaluation = what createU()+vecchia_likelihood_U() trigger per parameter
@@ -171,7 +173,9 @@ int gpv_plan_rows(gpv_plan *plan, int64_t *row_begin, int64_t *row_end);
 int gpv_plan_last_kernel_ms(gpv_plan *plan, double *ms);
 
 /* cond.yz='z' log-likelihood from the (all-reduced) sums; n = number of observations.
- * Closed form of R/vecchia_likelihood.R:63-99 when W = U_y U_y^T is diagonal. */
+ * Closed form of R/vecchia_likelihood.R:63-99 when W = U_y U_y^T is diagonal.
+ * sums[6] > 0 (some block was not positive definite) gives -Inf, like the reference: the failed row of Lentries
+ * stays zero (src/U_NZentries.cpp:64-66), diag(U) = 0, logdet.num = +Inf (R/vecchia_likelihood.R:76,95-96). */
 int gpv_loglik_z_from_sums(const double *sums, int64_t n, double *loglik);
 /* general form of R/vecchia_likelihood.R:95-96 from sums produced with GPV_WANT_DENOM */
 int gpv_loglik_from_sums(const double *sums, int64_t n, double *loglik);

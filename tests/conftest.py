@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# torch first: its wheel bundles a HIP runtime with the same soname (libamdhip64.so.7) as /opt/rocm's, which
+# libgpvecchia_hip.so links; whichever is loaded first serves both, the other order puts two runtimes in one process
+# and a torch stream handle handed to the library would belong to the wrong one
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -46,8 +46,8 @@ def test_status_strings_and_pure_host_entry_points():
     assert G.loglik_z_from_sums(s, 5) == pytest.approx(-0.5 * (10.0 + 7.0 + 5 * np.log(2 * np.pi)), rel=1e-15)
     ld, qf = G.numerator_from_sums(s)
     assert ld == pytest.approx(-2 * 1.5 - 4.0) and qf == pytest.approx(5.0)
-    s[6] = 1
-    assert np.isnan(G.loglik_z_from_sums(s, 5))
+    s[6] = 1         # a failed block: the reference's zero row gives logdet.num = +Inf, loglik = -Inf (R/vecchia_likelihood.R:76,95-96)
+    assert G.loglik_z_from_sums(s, 5) == -np.inf and G.loglik_from_sums(s, 5) == -np.inf
 
 
 @pytest.mark.skipif(__import__("gpvecchia_amd").device_count() > 0, reason="only meaningful without a GPU")

@@ -320,6 +320,29 @@ def test_failed_rows_and_errors():
     np.testing.assert_allclose(out["Lentries"][3], ref["Lentries"][3], rtol=1e-9, atol=1e-16)
 
 
+def test_failed_block_gives_minus_inf_loglik():
+    # a block that is not positive definite leaves a zero row in U (src/U_NZentries.cpp:64-66): diag(U) = 0,
+    # logdet.num = +Inf and the log-likelihood is -Inf (R/vecchia_likelihood.R:76,95-96), not NaN
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(3)
+    n, m = 200, 6
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    locs[57, 1] = np.nan                                   # NaN coordinate => NaN block => chol throws in the reference
+    va = R.vecchia_specify(np.nan_to_num(locs, nan=0.5), m, ordering="none", cond_yz="z")
+    va["locsord"] = locs
+    cp, tau = [1.0, 0.2, 1.5], 0.1
+    refU = R.createU(va, cp, tau)
+    assert refU["U_entries"]["n_failed"] >= 1
+    with np.errstate(divide="ignore"):
+        ll_ref = R.vecchia_likelihood_U(z, refU)
+    assert ll_ref == -np.inf
+    pva = _to_product_va(va)
+    assert G.vecchia_likelihood(z, pva, cp, tau) == -np.inf
+    plan = pva[("_plan", 0)]
+    assert plan.sums()[6] == refU["U_entries"]["n_failed"]
+
+
 def test_U_NZentries_mat():
     G = _need_gpu()
     from oracle import r_side as R
