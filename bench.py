@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--nu", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the mode U / mode S secondary measurements")
-    ap.add_argument("--cpu-budget-s", type=float, default=8.0,
+    ap.add_argument("--cpu-budget-s", type=float, default=10.0,
                     help="per-repeat wall budget of the CPU baseline; the whole data set is timed when it fits")
     ap.add_argument("--self-check", action="store_true",
                     help="N > 1: rank 0 also evaluates the unsharded plan and asserts the N-rank log-likelihood equals it to 1e-12")
@@ -378,7 +378,7 @@ def main():
                     sec["mode_S"] = {"error": repr(e)}
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.mode != "S":
-            cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - 4000, b), repeats=2)
+            cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - min(b - a - 2 * p, 60000), b), repeats=2)
             if n / cal["sets_per_s"] <= args.cpu_budget_s:
                 out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (0, n), repeats=3)
             else:

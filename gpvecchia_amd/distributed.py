@@ -65,6 +65,8 @@ class ShardedLikelihood:
             import torch
             if device is None:
                 device = int(os.environ.get("LOCAL_RANK", rank))
+            if not (0 <= int(device) < torch.cuda.device_count()):
+                raise ValueError(f"rank {rank}: GPU {device} does not exist ({torch.cuda.device_count()} visible)")
             torch.cuda.set_device(device)                  # RCCL reduces on the CURRENT device of each rank
         self.plan = plan_factory(self.row_begin, self.row_end)
         if self._nccl:
