@@ -149,7 +149,21 @@ def test_C2_full_size_all_rows_n1e5_m20():
                             np.full(n, tau), np.full(n, tau), "matern", cp)
         out = G.U_NZentries(1, n, locs, revNN, revCond, np.full(n, tau), np.full(n, tau), "matern", cp)
         assert out["n_failed"] == ref["n_failed"] == 0
-        assert _row_err(out["Lentries"], ref["Lentries"]) < ROW_TOL      # ALL 1e5 rows
+        # ALL 1e5 rows.  cond.yz='z': flat 1e-8.  SGV: neighbours conditioned on as latent carry no nugget, and at this
+        # density (spacing 0.003 against a range of 0.05) a few blocks reach cond(S) ~ 1e7..1e8, where two correct fp64
+        # factorisations differ by cond*eps: those rows get the condition-scaled bound
+        scale = np.maximum(np.abs(ref["Lentries"]).max(axis=1), 1e-300)
+        err = np.abs(out["Lentries"] - ref["Lentries"]).max(axis=1) / scale
+        if cond == "z":
+            assert err.max() < ROW_TOL
+        else:
+            hard = np.where(err >= ROW_TOL)[0]
+            assert hard.size <= n // 1000 and np.median(err) < 1e-11, (hard.size, err.max())
+            for k in hard:
+                okc = revNN[k] != 0
+                idx = revNN[k][okc] - 1
+                S_ = R.MaternFun(R.rdist(locs[idx]), cp) + np.diag(tau * (1 - revCond[k][okc]))
+                assert err[k] <= 32 * np.linalg.cond(S_) * np.finfo(float).eps, (k, err[k])
         np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
         np.testing.assert_allclose(out["Zentries"], ref["Zentries"], rtol=1e-15)
         if cond == "z":
