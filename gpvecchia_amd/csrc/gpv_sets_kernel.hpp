@@ -36,6 +36,7 @@
 #include "gpv_internal.h"
 #include "gpv_bessel.hpp"
 #include <type_traits>
+#include <utility>
 
 #ifndef GPV_MINW_SMALL
 #define GPV_MINW_SMALL 2      // launch_bounds waves/SIMD for P <= 32 (2 rows per lane => up to 256 VGPRs)
@@ -55,26 +56,66 @@
 
 namespace gpv {
 
+// DPP geometry: a set occupies exactly one 16-lane DPP row (4 sets per wave), lane i of the row owns the rows
+// i, i+16, i+32 of the block.  The wave-uniform-per-set operand of the elimination sweep (pivot-row element c =
+// register a[c/16][j] of lane c%16, by symmetry) is then read straight out of the other lane's register by the
+// 64-bit DPP control row_newbcast:(c%16) of v_fmac_f64_dpp: no LDS write, read or s_waitcnt in the sweep.
+#ifndef GPV_DPP
+#define GPV_DPP 1
+#endif
+#ifndef GPV_DPP_MINP
+#define GPV_DPP_MINP 22        // below: the denser lane packing of the LDS path wins (measured)
+#endif
+#ifndef GPV_DPP_MAXP
+#define GPV_DPP_MAXP 48        // 3 rows per lane; 4 rows of > 48 columns do not fit the 512 registers
+#endif
+__host__ __device__ constexpr bool k_dpp(int P) { return GPV_DPP != 0 && P >= GPV_DPP_MINP && P <= GPV_DPP_MAXP; }
+
 // geometry of one conditioning set inside a wavefront
 template <int P>
 struct Geo {
-    static constexpr int RPL = (P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1;         // rows per lane (measured: pays from P ~ 24)
+    static constexpr bool DPP = k_dpp(P);
+    static constexpr int RPL = DPP ? (P + 15) / 16 : ((P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1);   // rows per lane (LDS path: measured, pays from P ~ 24)
     static constexpr int LPS0 = (P + RPL - 1) / RPL;                            // lanes per set, minimal
     // one more lane per set when it costs no set per wave: guarantees a spare row slot for the data row
-    static constexpr int LPS = (LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0;
+    static constexpr int LPS = DPP ? 16 : ((LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0);
     static constexpr int SLOTS = LPS * RPL;                                     // row slots per set (>= P)
     static constexpr bool ZROW = SLOTS > P;                                     // slot P carries the data row
     static constexpr int SPW = 64 / LPS;                                        // sets per wave
-    static constexpr int MINW = (P <= 32) ? GPV_MINW_SMALL : (RPL == 2 ? 1 : GPV_MINW_LARGE);   // launch_bounds waves/SIMD
+    static constexpr int MINW = (P <= 32) ? GPV_MINW_SMALL : (RPL >= 2 ? 1 : GPV_MINW_LARGE);   // launch_bounds waves/SIMD
 };
 
-__host__ __device__ constexpr int k_lps(int P)
+// compile-time loop: f(std::integral_constant<int, B>{}), ..., f(std::integral_constant<int, E-1>{})
+template <int B, class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>)
 {
-    const int rpl = (P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1;
-    const int l0 = (P + rpl - 1) / rpl;
-    return (l0 * rpl == P && l0 < 64 && 64 / (l0 + 1) == 64 / l0) ? l0 + 1 : l0;
+    (f(std::integral_constant<int, B + Is>{}), ...);
 }
-__host__ __device__ constexpr int k_spw(int P) { return 64 / k_lps(P); }
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (E > B) static_for_impl<B>(f, std::make_integer_sequence<int, E - B>{});
+}
+
+// x of lane N of the caller's 16-lane DPP row, in every lane of that row.  The two wait states cover a VALU write of
+// the source by the preceding instruction (inline asm is invisible to hipcc's hazard recogniser: a VALU result needs
+// two wait states before a DPP read).  dep0/dep1 are not read: naming them orders every writer of the column the sweep
+// is about to read through DPP in front of this statement, and all those reads sit behind the reciprocal chain that
+// starts here, so no DPP read can follow its producer by less than two instructions.
+template <int N>
+__device__ __forceinline__ double dpp_row_bcast(double x, double dep0 = 0.0, double dep1 = 0.0)
+{
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+        : "=v"(r) : "v"(x), "n"(N), "v"(dep0), "v"(dep1));
+    return r;
+}
+// acc += (src of lane N of the DPP row) * w
+template <int N>
+__device__ __forceinline__ void dpp_fmac(double &acc, double src, double w)
+{
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w), "n"(N));
+}
 
 template <int P, int D, int COV>
 struct SetsLds {
@@ -549,49 +590,78 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         double prinv[RPL];                             // reciprocal of each row's own pivot (kept out of a[] indexing)
 #pragma unroll
         for (int q = 0; q < RPL; ++q) prinv[q] = 1.0;
+        double vlast;                                  // Schur complement of the point itself (row P-1)
+        double negmu_z = 0.0;                          // data row after the sweep: -mu_k (ZROW geometries)
+        if constexpr (G::DPP) {
+            // the pivot row never leaves the registers: element c of pivot row j is a[c/16][j] of lane c%16 (column j
+            // of the current matrix == pivot row by symmetry), fetched by the DPP row broadcast of each FMA
+            static_for<0, P - 1>([&](auto jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int qj = j / 16;                                  // the slot that holds pivot row j (in lane j%16)
+                const double pj = dpp_row_bcast<j % 16>(a[qj][j], a[(qj + 1) % RPL][j], a[(qj + 2) % RPL][j]);   // pivot = Schur complement d_j^2
+                const double rinv = rcp_pivot(pj);
+                const bool isp = (i == j % 16);
+                prinv[qj] = isp ? rinv : prinv[qj];
+                double nw[RPL];
 #pragma unroll
-        for (int j = 0; j < P - 1; ++j) {
-            double *cb = L.col[j & 1][sub];
+                for (int q = 0; q < RPL; ++q) {
+                    const double aj = (q == qj && isp) ? 0.0 : a[q][j];   // the pivot row itself is left untouched
+                    nw[q] = aj * -rinv;
+                }
+                static_for<j + 1, P>([&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
 #pragma unroll
-            for (int q = 0; q < RPL; ++q) cb[wslot[q]] = a[q][j];    // column j of the current matrix == pivot row by symmetry
+                    for (int q = 0; q < RPL; ++q) dpp_fmac<c % 16>(a[q][c], a[c / 16][j], nw[q]);
+                });
+            });
+            vlast = dpp_row_bcast<(P - 1) % 16>(a[(P - 1) / 16][P - 1]);
+            if constexpr (ZROW) negmu_z = dpp_row_bcast<P % 16>(a[P / 16][P - 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < P - 1; ++j) {
+                double *cb = L.col[j & 1][sub];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) cb[wslot[q]] = a[q][j];    // column j of the current matrix == pivot row by symmetry
+                wave_sync();
+                constexpr int CH = (P <= 32) ? GPV_CHUNK : 4;   // wide rows: keep the burst small, a[] already needs 2P VGPRs
+                double t[2][CH];
+                // burst 0 of the pivot row is in flight while the reciprocal is computed
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+                    if (j + 1 + u < P) t[0][u] = cb[j + 1 + u];
+                const double pj = cb[j];                   // pivot = Schur complement d_j^2
+                const double rinv = rcp_pivot(pj);
+                double w[RPL];
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const bool isp = (row[q] == j);
+                    prinv[q] = isp ? rinv : prinv[q];
+                    const double aj = isp ? 0.0 : a[q][j];   // the pivot row itself is left untouched
+                    w[q] = aj * rinv;
+                }
+#pragma unroll
+                for (int c0 = j + 1, b = 0; c0 < P; c0 += CH, b ^= 1) {
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+                        if (c0 + CH + u < P) t[b ^ 1][u] = cb[c0 + CH + u];      // next burst
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < CH; ++u)
+                        if (c0 + u < P) {
+#pragma unroll
+                            for (int q = 0; q < RPL; ++q) a[q][c0 + u] = __builtin_fma(-w[q], t[b][u], a[q][c0 + u]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // last column: slot P-1 = v (Schur complement of the point itself), slot P = -mu_k (data row)
+            double *cl = L.col[(P - 1) & 1][sub];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) cl[wslot[q]] = a[q][P - 1];
             wave_sync();
-            constexpr int CH = (P <= 32) ? GPV_CHUNK : 4;   // wide rows: keep the burst small, a[] already needs 2P VGPRs
-            double t[2][CH];
-            // burst 0 of the pivot row is in flight while the reciprocal is computed
-#pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (j + 1 + u < P) t[0][u] = cb[j + 1 + u];
-            const double pj = cb[j];                   // pivot = Schur complement d_j^2
-            const double rinv = rcp_pivot(pj);
-            double w[RPL];
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-                const bool isp = (row[q] == j);
-                prinv[q] = isp ? rinv : prinv[q];
-                const double aj = isp ? 0.0 : a[q][j];   // the pivot row itself is left untouched
-                w[q] = aj * rinv;
-            }
-#pragma unroll
-            for (int c0 = j + 1, b = 0; c0 < P; c0 += CH, b ^= 1) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + CH + u < P) t[b ^ 1][u] = cb[c0 + CH + u];      // next burst
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < CH; ++u)
-                    if (c0 + u < P) {
-#pragma unroll
-                        for (int q = 0; q < RPL; ++q) a[q][c0 + u] = __builtin_fma(-w[q], t[b][u], a[q][c0 + u]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            vlast = cl[P - 1];
+            if constexpr (ZROW) negmu_z = cl[P];
         }
-        // last column: slot P-1 = v (Schur complement of the point itself), slot P = -mu_k (data row)
-        double *cl = L.col[(P - 1) & 1][sub];
-#pragma unroll
-        for (int q = 0; q < RPL; ++q) cl[wslot[q]] = a[q][P - 1];
-        wave_sync();
-        const double vlast = cl[P - 1];
         bool bad = false;
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
@@ -625,7 +695,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         if (A.flags & 6) {
             double negmu;                              // -mu_k = -sum_j b_j z_j over observed-conditioned neighbours
             if constexpr (ZROW) {
-                negmu = cl[P];
+                negmu = negmu_z;
             } else {
                 // no spare slot: a_k = sum_j M_j z_j through LDS (R/vecchia_likelihood.R:74), -mu_k = a_k / d_k
                 double *cb = L.col[P & 1][sub];
