@@ -57,17 +57,20 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
         LIB = os.path.join(HERE, f"libgpvecchia_hip{tag}.so")
     extra_flags = list(extra_flags or [])
     os.makedirs(BUILD, exist_ok=True)
-    hdrs = [os.path.join(CSRC, f) for f in ("gpv_internal.h", "gpv_sets_kernel.hpp", "gpv_plist.h", "gpv_bessel.hpp")]
-    hdrs.append(os.path.join(os.path.dirname(HERE), "include", "gpvecchia.h"))
+    H = lambda *names: [os.path.join(CSRC, f) for f in names]
+    pub = os.path.join(os.path.dirname(HERE), "include", "gpvecchia.h")
+    internal = H("gpv_internal.h", "gpv_bessel.hpp")
+    kern = internal + H("gpv_sets_kernel.hpp")                       # what the conditioning-set kernel TUs include
     work = []
     for P in plist():
         work.append((os.path.join(CSRC, "gpv_sets_inst.hip"), os.path.join(BUILD, f"sets_p{P}.o"),
-                     [f"-DGPV_INST_P={P}"] + extra_flags, hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), [], hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_order.cpp"), os.path.join(BUILD, "order.o"), ["-x", "c++"], hdrs, force))
-    work.append((os.path.join(CSRC, "gpv_nn.hip"), os.path.join(BUILD, "nn.o"), ["-ffp-contract=off"], hdrs, force))
+                     [f"-DGPV_INST_P={P}"] + extra_flags, kern, force))
+    work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), list(extra_flags),
+                 kern + H("gpv_plist.h"), force))
+    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub], force))
+    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), internal, force))
+    work.append((os.path.join(CSRC, "gpv_order.cpp"), os.path.join(BUILD, "order.o"), ["-x", "c++"], [pub], force))
+    work.append((os.path.join(CSRC, "gpv_nn.hip"), os.path.join(BUILD, "nn.o"), ["-ffp-contract=off"], internal + [pub], force))
     jobs = jobs or min(8, os.cpu_count() or 1)
     with ThreadPoolExecutor(jobs) as ex:
         res = list(ex.map(_compile, work))

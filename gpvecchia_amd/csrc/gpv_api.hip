@@ -149,6 +149,66 @@ void sort_order_by_key(const uint64_t *key, int64_t n, int32_t *order)
     for (int64_t i = 0; i < n; ++i) order[i] = src[i].i;
 }
 
+// 128-bit content hash of a host buffer, chunks hashed by separate threads and combined in chunk order.
+// Two independent multiply-rotate lanes over 8-byte words (not cryptographic: it keys the plan cache of the literal
+// drop-in, where a false hit needs a 2^-128 collision between two different index arrays of the same shape).
+struct Hash128 {
+    uint64_t a = 0, b = 0;
+    bool operator==(const Hash128 &o) const { return a == o.a && b == o.b; }
+};
+inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+Hash128 hash_bytes(const void *ptr, size_t bytes, uint64_t seed)
+{
+    const unsigned char *p = static_cast<const unsigned char *>(ptr);
+    const size_t words = bytes / 8;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? (hw > 32 ? 32 : hw) : 4;
+    if (bytes < ((size_t)1 << 22)) nt = 1;
+    std::vector<Hash128> part(nt);
+    const size_t chunk = (words + nt - 1) / nt;
+    auto work = [&](size_t t) {
+        const size_t lo = t * chunk, hi = (lo + chunk < words) ? lo + chunk : words;
+        uint64_t h0 = seed ^ 0x9E3779B97F4A7C15ull, h1 = seed + 0xD6E8FEB86659FD93ull;
+        uint64_t g0 = ~seed, g1 = seed * 0xFF51AFD7ED558CCDull + 1;
+        size_t i = lo;
+        for (; i + 2 <= hi; i += 2) {
+            uint64_t v0, v1;
+            std::memcpy(&v0, p + 8 * i, 8);
+            std::memcpy(&v1, p + 8 * i + 8, 8);
+            h0 = rotl64(h0 ^ (v0 * 0x9E3779B97F4A7C15ull), 27) * 0xC2B2AE3D27D4EB4Full;
+            h1 = rotl64(h1 ^ (v1 * 0xD6E8FEB86659FD93ull), 31) * 0x165667B19E3779F9ull;
+            g0 = rotl64(g0 + v0, 29) * 0xFF51AFD7ED558CCDull ^ v1;
+            g1 = rotl64(g1 + v1, 23) * 0xC4CEB9FE1A85EC53ull ^ v0;
+        }
+        for (; i < hi; ++i) {
+            uint64_t v0;
+            std::memcpy(&v0, p + 8 * i, 8);
+            h0 = rotl64(h0 ^ (v0 * 0x9E3779B97F4A7C15ull), 27) * 0xC2B2AE3D27D4EB4Full;
+            g0 = rotl64(g0 + v0, 29) * 0xFF51AFD7ED558CCDull;
+        }
+        part[t].a = h0 ^ rotl64(h1, 17);
+        part[t].b = g0 ^ rotl64(g1, 41);
+    };
+    if (nt == 1) work(0);
+    else {
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    Hash128 r;
+    r.a = seed ^ (uint64_t)bytes;
+    r.b = ~seed + (uint64_t)bytes;
+    for (size_t t = 0; t < nt; ++t) {
+        r.a = rotl64(r.a ^ part[t].a, 25) * 0x9E3779B97F4A7C15ull + t;
+        r.b = rotl64(r.b + part[t].b, 37) * 0xC2B2AE3D27D4EB4Full ^ t;
+    }
+    uint64_t tail = 0;                                        // the last bytes % 8 bytes
+    std::memcpy(&tail, p + 8 * words, bytes - 8 * words);
+    r.a ^= tail * 0xD6E8FEB86659FD93ull;
+    r.b += rotl64(tail, 13);
+    return r;
+}
+
 }  // namespace
 
 struct gpv_plan {
@@ -939,9 +999,51 @@ int gpv_numerator_from_sums(const double *s, double *logdet_num, double *quadfor
 // ---------------------------------------------------------------------------------------
 // literal drop-ins
 // ---------------------------------------------------------------------------------------
+// Plan cache of the literal drop-in.  An unmodified R createU (R/createU.R:152-154) hands the same locsord / revNNarray /
+// revCondOnLatent to U_NZentries at every optimiser step (vecchia_estimate: up to 300 calls, R/vecchia_wrappers.R:87-93);
+// the device plan built from them (Morton order, index re-layout, uploads: ~100 ms at n = 1e6) is kept and reused while
+// shape and a 128-bit content hash of the three arrays match.  One entry; GPV_NO_PLAN_CACHE=1 disables it;
+// gpv_plan_cache_clear() frees the device memory it holds.
+namespace {
+struct PlanCache {
+    std::mutex mu;
+    gpv_plan *pl = nullptr;
+    int64_t Nlocs = 0;
+    int dim = 0, ncol = 0;
+    Hash128 h_locs, h_nn, h_cond;
+    int64_t hits = 0, misses = 0;
+};
+PlanCache g_cache;
+}  // namespace
+
+int gpv_plan_cache_clear(void)
+{
+    std::lock_guard<std::mutex> g(g_cache.mu);
+    if (g_cache.pl) gpv_plan_destroy(g_cache.pl);
+    g_cache.pl = nullptr;
+    return GPV_OK;
+}
+
+int gpv_plan_cache_stats(int64_t *hits, int64_t *misses)
+{
+    std::lock_guard<std::mutex> g(g_cache.mu);
+    if (hits) *hits = g_cache.hits;
+    if (misses) *misses = g_cache.misses;
+    return GPV_OK;
+}
+
 static int zentries_host(gpv_plan *pl, const double *nuggets_obsord, int64_t n, double *Zentries)
 {
     if (n <= 0) return GPV_OK;
+    if (n <= pl->Nlocs && n <= pl->rows) {
+        // the plan's own buffers: no allocation on the (cached) hot path of the drop-in
+        if (!pl->d_Z) GPV_HIP(hipMalloc((void **)&pl->d_Z, sizeof(double) * 2 * (size_t)pl->rows));
+        GPV_HIP(hipMemcpyAsync(pl->d_stage, nuggets_obsord, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, pl->stream));
+        GPV_HIP(launch_zentries(pl->d_stage, n, pl->d_Z, pl->stream));
+        GPV_HIP(hipMemcpyAsync(Zentries, pl->d_Z, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, pl->stream));
+        GPV_HIP(hipStreamSynchronize(pl->stream));
+        return GPV_OK;
+    }
     double *d_n = nullptr, *d_Z = nullptr;
     GPV_HIP(hipMalloc((void **)&d_n, sizeof(double) * (size_t)n));
     if (hipMalloc((void **)&d_Z, sizeof(double) * 2 * (size_t)n) != hipSuccess) {
@@ -977,8 +1079,36 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
     if (rc != GPV_OK) { *status = rc; return; }
     gpv_plan *pl = nullptr;
     PhaseTimer tm;
-    rc = gpv_plan_create(&pl, 0, *Nlocs, *dim, *ncolNN, locs, revNNarray, revCondOnLatent, 0, *Nlocs);
-    if (rc != GPV_OK) { *status = rc; return; }
+    static const bool no_cache = getenv("GPV_NO_PLAN_CACHE") != nullptr;
+    std::unique_lock<std::mutex> cache_lock(g_cache.mu, std::defer_lock);
+    bool cached = false;
+    if (!no_cache && *Nlocs > 0 && *dim > 0 && *ncolNN > 0) {
+        cache_lock.lock();                                   // the cached plan is in use until this call returns
+        const size_t nl = (size_t)*Nlocs;
+        const Hash128 hl = hash_bytes(locs, nl * (size_t)*dim * sizeof(double), 1);
+        const Hash128 hn = hash_bytes(revNNarray, nl * (size_t)*ncolNN * sizeof(int), 2);
+        const Hash128 hc = hash_bytes(revCondOnLatent, nl * (size_t)*ncolNN * sizeof(int), 3);
+        tm.lap("drop-in: content hash");
+        if (g_cache.pl && g_cache.Nlocs == *Nlocs && g_cache.dim == *dim && g_cache.ncol == *ncolNN && g_cache.h_locs == hl &&
+            g_cache.h_nn == hn && g_cache.h_cond == hc) {
+            pl = g_cache.pl;
+            cached = true;
+            ++g_cache.hits;
+        } else {
+            if (g_cache.pl) gpv_plan_destroy(g_cache.pl);
+            g_cache.pl = nullptr;
+            ++g_cache.misses;
+            rc = gpv_plan_create(&pl, 0, *Nlocs, *dim, *ncolNN, locs, revNNarray, revCondOnLatent, 0, *Nlocs);
+            if (rc != GPV_OK) { *status = rc; return; }
+            g_cache.pl = pl;
+            g_cache.Nlocs = *Nlocs; g_cache.dim = *dim; g_cache.ncol = *ncolNN;
+            g_cache.h_locs = hl; g_cache.h_nn = hn; g_cache.h_cond = hc;
+            cached = true;                                   // owned by the cache from here on
+        }
+    } else {
+        rc = gpv_plan_create(&pl, 0, *Nlocs, *dim, *ncolNN, locs, revNNarray, revCondOnLatent, 0, *Nlocs);
+        if (rc != GPV_OK) { *status = rc; return; }
+    }
     tm.lap("drop-in: plan");
     rc = plan_eval_impl(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
     if (rc == GPV_OK && tm.on) (void)hipStreamSynchronize(pl->stream);
@@ -990,7 +1120,12 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
     if (rc == GPV_OK) rc = zentries_host(pl, nuggets_obsord, *n, Zentries);
     if (rc == GPV_OK && n_failed) *n_failed = (int)sums[6];
     tm.lap("drop-in: Zentries");
-    gpv_plan_destroy(pl);
+    if (!cached) {
+        gpv_plan_destroy(pl);
+    } else if (rc != GPV_OK) {                               // do not keep a plan whose evaluation failed
+        gpv_plan_destroy(pl);
+        g_cache.pl = nullptr;
+    }
     tm.lap("drop-in: destroy");
     *status = rc;
 }

@@ -56,10 +56,12 @@
 
 namespace gpv {
 
-// DPP geometry: a set occupies exactly one 16-lane DPP row (4 sets per wave), lane i of the row owns the rows
-// i, i+16, i+32 of the block.  The wave-uniform-per-set operand of the elimination sweep (pivot-row element c =
-// register a[c/16][j] of lane c%16, by symmetry) is then read straight out of the other lane's register by the
-// 64-bit DPP control row_newbcast:(c%16) of v_fmac_f64_dpp: no LDS write, read or s_waitcnt in the sweep.
+// DPP geometries.  16 lanes (22 <= P <= 48): a set occupies exactly one 16-lane DPP row (4 sets per wave), lane i of the
+// row owns the rows i, i+16, i+32 of the block.  The wave-uniform-per-set operand of the elimination sweep (pivot-row
+// element c = register a[c/16][j] of lane c%16, by symmetry) is then read straight out of the other lane's register by
+// the 64-bit DPP control row_newbcast:(c%16) of v_fmac_f64_dpp: no LDS write, read or s_waitcnt in the sweep.
+// 32 lanes (49 <= P <= 64): a set is a PAIR of DPP rows (2 sets per wave), lane i owns rows i and i+32; per pivot one
+// v_permlane16_swap per 32-bit half leaves column j of both DPP rows in both of them, then the same DPP FMAs.
 #ifndef GPV_DPP
 #define GPV_DPP 1
 #endif
@@ -69,16 +71,21 @@ namespace gpv {
 #ifndef GPV_DPP_MAXP
 #define GPV_DPP_MAXP 48        // 3 rows per lane; 4 rows of > 48 columns do not fit the 512 registers
 #endif
+#ifndef GPV_DPP2
+#define GPV_DPP2 1
+#endif
 __host__ __device__ constexpr bool k_dpp(int P) { return GPV_DPP != 0 && P >= GPV_DPP_MINP && P <= GPV_DPP_MAXP; }
+__host__ __device__ constexpr bool k_dpp2(int P) { return GPV_DPP != 0 && GPV_DPP2 != 0 && P > GPV_DPP_MAXP && P > 32 && P <= 64; }
 
 // geometry of one conditioning set inside a wavefront
 template <int P>
 struct Geo {
-    static constexpr bool DPP = k_dpp(P);
-    static constexpr int RPL = DPP ? (P + 15) / 16 : ((P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1);   // rows per lane (LDS path: measured, pays from P ~ 24)
+    static constexpr bool DPP2 = k_dpp2(P);
+    static constexpr bool DPP = k_dpp(P) || DPP2;
+    static constexpr int RPL = DPP2 ? 2 : (DPP ? (P + 15) / 16 : ((P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1));   // rows per lane (LDS path: measured, pays from P ~ 24)
     static constexpr int LPS0 = (P + RPL - 1) / RPL;                            // lanes per set, minimal
     // one more lane per set when it costs no set per wave: guarantees a spare row slot for the data row
-    static constexpr int LPS = DPP ? 16 : ((LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0);
+    static constexpr int LPS = DPP2 ? 32 : (DPP ? 16 : ((LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0));
     static constexpr int SLOTS = LPS * RPL;                                     // row slots per set (>= P)
     static constexpr bool ZROW = SLOTS > P;                                     // slot P carries the data row
     static constexpr int SPW = 64 / LPS;                                        // sets per wave
@@ -103,12 +110,38 @@ __device__ __forceinline__ void static_for(F &&f)
 // is about to read through DPP in front of this statement, and all those reads sit behind the reciprocal chain that
 // starts here, so no DPP read can follow its producer by less than two instructions.
 template <int N>
-__device__ __forceinline__ double dpp_row_bcast(double x, double dep0 = 0.0, double dep1 = 0.0)
+__device__ __forceinline__ double dpp_row_bcast(double x, double dep0 = 0.0, double dep1 = 0.0, double dep2 = 0.0, double dep3 = 0.0)
 {
     double r;
     asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
-        : "=v"(r) : "v"(x), "n"(N), "v"(dep0), "v"(dep1));
+        : "=v"(r) : "v"(x), "n"(N), "v"(dep0), "v"(dep1), "v"(dep2), "v"(dep3));
     return r;
+}
+// x of both DPP rows of a row pair, in both of them: lo = x of the even row (lanes 0-15 / 32-47), hi = x of the odd row
+// (lanes 16-31 / 48-63) at the same position in the row.  v_permlane16_swap_b32 swaps the odd rows of its first operand
+// with the even rows of its second; on two copies of x that is exactly (lo, hi).
+struct RowPair { double lo, hi; };
+__device__ __forceinline__ RowPair dpp_rowpair(double x)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned l = (unsigned)u, h = (unsigned)(u >> 32);
+    const auto rl = __builtin_amdgcn_permlane16_swap(l, l, false, false);
+    const auto rh = __builtin_amdgcn_permlane16_swap(h, h, false, false);
+    RowPair r;
+    r.lo = __builtin_bit_cast(double, ((unsigned long long)rh[0] << 32) | rl[0]);
+    r.hi = __builtin_bit_cast(double, ((unsigned long long)rh[1] << 32) | rl[1]);
+    return r;
+}
+// x of lane LN (0 .. LPS-1) of the caller's set, in every lane of the set (LPS = 16: one DPP row, 32: a row pair)
+template <int LPS, int LN>
+__device__ __forceinline__ double set_bcast(double x)
+{
+    if constexpr (LPS == 16) {
+        return dpp_row_bcast<LN>(x);
+    } else {
+        const RowPair y = dpp_rowpair(x);
+        return dpp_row_bcast<LN % 16>(LN < 16 ? y.lo : y.hi);
+    }
 }
 // acc += (src of lane N of the DPP row) * w
 template <int N>
@@ -237,6 +270,37 @@ __device__ __forceinline__ double exp_neg(double t)
     return __builtin_ldexp(p, (int)kd);
 }
 
+// Running sum of logarithms without a log per term: log(x_1 ... x_T) = log(prod) + esum ln 2 with the product kept in
+// [0.5, 1) (mantissa/exponent split of every factor, one conditional doubling per step).  Each step rounds the product
+// once, so T terms carry T/2 ulp: far below the 1e-8 the likelihood needs, and the one log is taken after the task loop.
+// x = 0 (-Inf), Inf (+Inf) and NaN stick, like log would.
+struct LogAcc {
+    double prod = 0.5;
+    int esum = 1;                                   // log(0.5 * 2^1) = 0
+    __device__ __forceinline__ void mul(double x, bool on)
+    {
+        const double m = on ? __builtin_amdgcn_frexp_mant(x) : 1.0;      // [0.5, 1); 1.0 = neutral (renormalised below)
+        const int e = on ? __builtin_amdgcn_frexp_exp(x) : 0;
+        double p = prod * m;                                              // [0.25, 1]
+        const int up = (p < 0.5) ? 1 : 0;
+        prod = __builtin_ldexp(p, up);
+        esum += e - up;
+    }
+    __device__ __forceinline__ double value() const { return log(prod) + (double)esum * 0.6931471805599453094; }
+};
+
+// 1/x to ~1 ulp for the likelihood terms: v_rcp_f64 + two Newton steps; x = 0 -> Inf and x = Inf -> 0 survive (the
+// Newton residual is NaN there and the raw v_rcp_f64 result is kept), NaN stays NaN
+__device__ __forceinline__ double rcp_safe(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r0, 1.0);
+    double r = __builtin_fma(r0, e, r0);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return (r == r) ? r : r0;
+}
+
 // general-nu Matern through the per-launch table (gpv_bessel.hpp, MaternTab); outside its range the series path
 __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_base, int mt_nseg, const BesselTab &bt,
                                                      double s, double normcon, double nu)
@@ -337,6 +401,14 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
     for (int q = lane; q < (Lds::NEEDZERO ? COLS : 2); q += 64) L.zero[q] = 0.0;
+
+    // likelihood partial sums live in the registers of the lane that owns row P-1 of its set (slot QO of lane IO of
+    // the set) for the whole task loop; the other lanes run the same instructions on their own rows' values and
+    // their accumulators are never read.  No LDS read-modify-write and no log() per conditioning set.
+    constexpr int QO = (P - 1) / LPS, IO = (P - 1) % LPS;
+    LogAcc lg_d, lg_tv, lg_tau;                        // sums[0] log d_k, sums[2] log(tau + v), sums[5] log tau
+    double acc_a2 = 0.0, acc_rz = 0.0, acc_z2 = 0.0;   // sums[1], sums[3], sums[4]
+    int acc_fail = 0, acc_rows = 0;                    // sums[6], sums[7]
 
     const int64_t ntasks = (A.rows + SPW - 1) / SPW;
     for (int64_t task = (int64_t)blockIdx.x * W + wv; task < ntasks; task += (int64_t)gridDim.x * W) {
@@ -597,10 +669,25 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             // of the current matrix == pivot row by symmetry), fetched by the DPP row broadcast of each FMA
             static_for<0, P - 1>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
-                constexpr int qj = j / 16;                                  // the slot that holds pivot row j (in lane j%16)
-                const double pj = dpp_row_bcast<j % 16>(a[qj][j], a[(qj + 1) % RPL][j], a[(qj + 2) % RPL][j]);   // pivot = Schur complement d_j^2
+                constexpr int qj = j / LPS;                                 // the slot that holds pivot row j (in lane j % LPS)
+                double pj;                                                  // pivot = Schur complement d_j^2
+                double ylo[RPL], yhi[RPL];                                  // LPS = 32: column j of the even / odd DPP row
+                if constexpr (LPS == 16) {
+                    pj = dpp_row_bcast<j % 16>(a[qj][j], a[(qj + 1) % RPL][j], a[(qj + 2) % RPL][j]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        ylo[q] = yhi[q] = 0.0;
+                        if (q >= qj) {                                      // slots below hold no column > j any more
+                            const RowPair y = dpp_rowpair(a[q][j]);
+                            ylo[q] = y.lo;
+                            yhi[q] = y.hi;
+                        }
+                    }
+                    pj = dpp_row_bcast<j % 16>((j % 32) < 16 ? ylo[qj] : yhi[qj], ylo[0], yhi[0], ylo[RPL - 1], yhi[RPL - 1]);
+                }
                 const double rinv = rcp_pivot(pj);
-                const bool isp = (i == j % 16);
+                const bool isp = (i == j % LPS);
                 prinv[qj] = isp ? rinv : prinv[qj];
                 double nw[RPL];
 #pragma unroll
@@ -611,11 +698,14 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 static_for<j + 1, P>([&](auto cc) __attribute__((always_inline)) {
                     constexpr int c = decltype(cc)::value;
 #pragma unroll
-                    for (int q = 0; q < RPL; ++q) dpp_fmac<c % 16>(a[q][c], a[c / 16][j], nw[q]);
+                    for (int q = 0; q < RPL; ++q) {
+                        if constexpr (LPS == 16) dpp_fmac<c % 16>(a[q][c], a[c / 16][j], nw[q]);
+                        else dpp_fmac<c % 16>(a[q][c], (c % 32) < 16 ? ylo[c / 32] : yhi[c / 32], nw[q]);
+                    }
                 });
             });
-            vlast = dpp_row_bcast<(P - 1) % 16>(a[(P - 1) / 16][P - 1]);
-            if constexpr (ZROW) negmu_z = dpp_row_bcast<P % 16>(a[P / 16][P - 1]);
+            vlast = set_bcast<LPS, (P - 1) % LPS>(a[(P - 1) / LPS][P - 1]);
+            if constexpr (ZROW) negmu_z = set_bcast<LPS, P % LPS>(a[P / LPS][P - 1]);
         } else {
 #pragma unroll
             for (int j = 0; j < P - 1; ++j) {
@@ -708,43 +798,41 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 for (int c = 0; c < P - 1; ++c) ak += cb[c];
                 negmu = ak * dlast;
             }
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-                if (set_on && row[q] == P - 1) {
-                    double *ac = L.acc[sub];
-                    if (fail) {
-                        ac[6] += 1.0;
-                        if (A.aout != nullptr) A.aout[A.rowid[k]] = 0.0;
-                    } else {
-                        const double tau = nugraw[q];
-                        const double tv = tau + vlast;
-                        const double rz = zi[q] + negmu;             // z_k - mu_k
-                        if (A.aout != nullptr) A.aout[A.rowid[k]] = negmu * rs;
-                        if (A.flags & 2) {
-                            ac[2] += log(tv);
-                            ac[3] += rz * rz / tv;
-                        }
-                        if (A.flags & 4) {
-                            const double ak = negmu * rs;            // a_k = -mu_k d_k
-                            ac[0] += log(rs);
-                            ac[1] += ak * ak;
-                            ac[4] += zi[q] * zi[q] / tau;
-                            ac[5] += log(tau);
-                        }
-                    }
-                    ac[7] += 1.0;
+            {
+                const bool good = set_on && !fail;
+                const double tau = nugraw[QO];
+                const double zk = zi[QO];
+                if (A.aout != nullptr && set_on && i == IO) A.aout[A.rowid[k]] = fail ? 0.0 : negmu * rs;
+                if (A.flags & 2) {
+                    const double tv = tau + vlast;
+                    const double rz = zk + negmu;                    // z_k - mu_k
+                    lg_tv.mul(tv, good);
+                    const double t3 = rz * rz * rcp_safe(tv);
+                    acc_rz += good ? t3 : 0.0;
                 }
-            }
-            wave_sync();
-        } else {
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-                if (set_on && row[q] == P - 1) {
-                    if (fail) L.acc[sub][6] += 1.0;
-                    L.acc[sub][7] += 1.0;
+                if (A.flags & 4) {
+                    const double ak = negmu * rs;                    // a_k = -mu_k d_k
+                    lg_d.mul(rs, good);
+                    lg_tau.mul(tau, good);
+                    const double t1 = ak * ak, t4 = zk * zk * rcp_safe(tau);
+                    acc_a2 += good ? t1 : 0.0;
+                    acc_z2 += good ? t4 : 0.0;
                 }
             }
         }
+        acc_fail += (set_on && fail) ? 1 : 0;
+        acc_rows += set_on ? 1 : 0;
+    }
+    if (lane_on && i_const == IO) {
+        double *ac = L.acc[sub];
+        ac[0] = (A.flags & 4) ? lg_d.value() : 0.0;
+        ac[1] = acc_a2;
+        ac[2] = (A.flags & 2) ? lg_tv.value() : 0.0;
+        ac[3] = acc_rz;
+        ac[4] = acc_z2;
+        ac[5] = (A.flags & 4) ? lg_tau.value() : 0.0;
+        ac[6] = (double)acc_fail;
+        ac[7] = (double)acc_rows;
     }
 
     // ---- deterministic block reduction of the partial sums ----------------------------

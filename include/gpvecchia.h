@@ -103,6 +103,14 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
                      const double *covparms, const int *ncovparms, double *Lentries, double *Zentries,
                      int *n_failed, int *status);
 
+/* gpv_U_NZentries keeps the device plan it builds from (locs, revNNarray, revCondOnLatent) and reuses it while the next
+ * call passes arrays of the same shape and content (128-bit hash): an unmodified createU (R/createU.R:152-154) called
+ * once per optimiser step by vecchia_estimate (R/vecchia_wrappers.R:72-93) pays the re-layout once.  The cached plan
+ * holds device memory (about 0.5 GB at Nlocs = 1e6, m = 30) until the next different call or gpv_plan_cache_clear();
+ * the environment variable GPV_NO_PLAN_CACHE=1 disables the cache.  Calls are serialised on the cache. */
+int gpv_plan_cache_clear(void);
+int gpv_plan_cache_stats(int64_t *hits, int64_t *misses);   /* counters since load (either pointer may be NULL) */
+
 /* Replaces: _GPvecchia_U_NZentries_mat (src/RcppExports.cpp:70-86), R/RcppExports.R:26-28,
  * body src/U_NZentries.cpp:126-197, call site R/createU.R:149-151.
  * covVals is the dense Nlocs x Nlocs covariance (column-major); no nugget is added (:144);

@@ -343,6 +343,65 @@ def test_failed_block_gives_minus_inf_loglik():
     assert plan.sums()[6] == refU["U_entries"]["n_failed"]
 
 
+def _cache_stats():
+    import ctypes as C
+    from gpvecchia_amd import _lib
+    h, m = C.c_int64(), C.c_int64()
+    _lib.lib().gpv_plan_cache_stats(C.byref(h), C.byref(m))
+    return h.value, m.value
+
+
+def test_literal_dropin_plan_cache():
+    # gpv_U_NZentries keeps the plan of the last (locs, revNNarray, revCondOnLatent): an unmodified createU
+    # (R/createU.R:152-154) called once per optimiser step re-lays the index arrays out once.  Any change of a single
+    # index, flag or coordinate must miss.
+    G = _need_gpu()
+    from gpvecchia_amd import _lib
+    from oracle import r_side as R
+    n, m = 3000, 20
+    locs, z, va = _case(n, m, 2, 91, "SGV")
+    prep = va["U_prep"]
+    nn = np.nan_to_num(prep["revNNarray"]).astype(np.int32)
+    cd = np.nan_to_num(prep["revCond"], nan=-1.0).astype(np.int8)
+    tau = np.full(n, 0.1)
+    call = lambda l_, n_, c_, cp, t_: G.U_NZentries(1, n, l_, n_, c_, t_, t_, "matern", cp)
+    _lib.lib().gpv_plan_cache_clear()
+    h0, m0 = _cache_stats()
+    a = call(va["locsord"], nn, cd, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0, m0 + 1)
+    b = call(va["locsord"], nn, cd, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0 + 1, m0 + 1) and np.array_equal(a["Lentries"], b["Lentries"])
+    # other covariance parameters / nuggets: same plan
+    c = call(va["locsord"], nn, cd, [2.0, 0.2, 0.5], 0.05 + np.random.default_rng(1).random(n))
+    assert _cache_stats() == (h0 + 2, m0 + 1)
+    ref = R.U_NZentries(1, n, va["locsord"], nn, np.where(cd < 0, 0, cd), 0.05 + np.random.default_rng(1).random(n),
+                        tau, "matern", [2.0, 0.2, 0.5])
+    assert _row_err(c["Lentries"], ref["Lentries"]) < 1e-7
+    # one neighbour index changed (row 2000: the farthest neighbour replaced by another earlier point)
+    nn2 = nn.copy()
+    used = set(nn2[2000].tolist())
+    nn2[2000, 0] = next(v for v in range(1, 2000) if v not in used)
+    d = call(va["locsord"], nn2, cd, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0 + 2, m0 + 2)
+    ref2 = R.U_NZentries(1, n, va["locsord"], nn2, np.where(cd < 0, 0, cd), tau, tau, "matern", [1.0, 0.1, 1.5])
+    assert _row_err(d["Lentries"], ref2["Lentries"]) < 1e-7 and not np.array_equal(d["Lentries"][2000], a["Lentries"][2000])
+    same = np.ones(n, bool); same[2000] = False
+    assert np.array_equal(d["Lentries"][same], a["Lentries"][same])
+    # one cond flag, one coordinate
+    cd2 = cd.copy(); cd2[1500, 3] = 1 - cd2[1500, 3]
+    call(va["locsord"], nn, cd2, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0 + 2, m0 + 3)
+    l2 = va["locsord"].copy(); l2[77, 1] = np.nextafter(l2[77, 1], 2.0)
+    call(l2, nn, cd2, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0 + 2, m0 + 4)
+    call(l2, nn, cd2, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0 + 3, m0 + 4)
+    _lib.lib().gpv_plan_cache_clear()
+    e = call(l2, nn, cd2, [1.0, 0.1, 1.5], tau)
+    assert _cache_stats() == (h0 + 3, m0 + 5)
+    _lib.lib().gpv_plan_cache_clear()
+
+
 def test_U_NZentries_mat():
     G = _need_gpu()
     from oracle import r_side as R
