@@ -21,6 +21,7 @@ BUILD = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libgpvecchia_hip.so")
 ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+SPLIT_FROM_P = 41          # row lengths from here on compile one TU per spatial dimension (minutes per instantiation)
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-variable"]
 
 
@@ -62,13 +63,21 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
     internal = H("gpv_internal.h", "gpv_bessel.hpp")
     kern = internal + H("gpv_sets_kernel.hpp")                       # what the conditioning-set kernel TUs include
     work = []
-    for P in plist():
-        work.append((os.path.join(CSRC, "gpv_sets_inst.hip"), os.path.join(BUILD, f"sets_p{P}.o"),
-                     [f"-DGPV_INST_P={P}"] + extra_flags, kern, force))
+    inst = os.path.join(CSRC, "gpv_sets_inst.hip")
+    for P in sorted(plist(), reverse=True):          # longest compiles first
+        if P >= SPLIT_FROM_P:                        # one TU per spatial dimension + the function that picks among them
+            for d in (3, 2, 1, 0):
+                work.append((inst, os.path.join(BUILD, f"sets_p{P}_d{d}.o"),
+                             [f"-DGPV_INST_P={P}", f"-DGPV_INST_DIM={d}"] + extra_flags, kern, force))
+            work.append((inst, os.path.join(BUILD, f"sets_p{P}.o"), [f"-DGPV_INST_P={P}", "-DGPV_INST_DISPATCH"] + extra_flags,
+                         kern, force))
+        else:
+            work.append((inst, os.path.join(BUILD, f"sets_p{P}.o"), [f"-DGPV_INST_P={P}"] + extra_flags, kern, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), list(extra_flags),
                  kern + H("gpv_plist.h"), force))
-    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub], force))
+    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub] + H("gpv_laplace.h"), force))
     work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), internal, force))
+    work.append((os.path.join(CSRC, "gpv_laplace.hip"), os.path.join(BUILD, "laplace.o"), [], H("gpv_laplace.h"), force))
     work.append((os.path.join(CSRC, "gpv_order.cpp"), os.path.join(BUILD, "order.o"), ["-x", "c++"], [pub], force))
     work.append((os.path.join(CSRC, "gpv_nn.hip"), os.path.join(BUILD, "nn.o"), ["-ffp-contract=off"], internal + [pub], force))
     jobs = jobs or min(8, os.cpu_count() or 1)

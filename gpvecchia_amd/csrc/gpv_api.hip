@@ -4,6 +4,7 @@
 // There is no CPU compute path in here: without a GPU every entry fails loudly.
 #include "../../include/gpvecchia.h"
 #include "gpv_internal.h"
+#include "gpv_laplace.h"
 
 #include <chrono>
 #include <climits>
@@ -251,6 +252,11 @@ struct gpv_plan {
     double nug_scalar = 0.0;
     bool nug_is_scalar = true;
     uint8_t *d_cond = nullptr;
+    // Vecchia-Laplace state (gpv_plan_vl_begin): data z, prior mean, two latent-mean buffers (current / next), flags + max
+    double *d_vl_z = nullptr, *d_vl_pm = nullptr, *d_vl_y[2] = {nullptr, nullptr}, *d_vl_out = nullptr;
+    int *d_vl_flags = nullptr;
+    int vl_model = -1, vl_cur = 0;
+    double vl_alpha = 2.0, vl_sigma = 0.0;
     bool has_z = false, evaluated = false, have_U = false;
     hipStream_t last_stream = nullptr;
 };
@@ -298,7 +304,8 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt};
+                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt,
+                    pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -551,10 +558,12 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         GPV_HIP(hipMalloc((void **)&pl->d_L, sizeof(double) * (size_t)(pl->rows > 0 ? pl->rows : 1) * pl->P));
     }
     if (cs.cov != COV_DENSE) {
-        if (!nuggets) return GPV_ERR_BAD_ARG;
+        if (!nuggets && n_nuggets != -1) return GPV_ERR_BAD_ARG;
         if (n_nuggets == 1) {
             pl->nug_is_scalar = true;                                         // R/createU.R:74
             pl->nug_scalar = nuggets[0];
+        } else if (n_nuggets == -1 && pl->d_nug_user) {
+            pl->nug_is_scalar = false;                                        // per-location nuggets already in HBM (VL step)
         } else if (n_nuggets == pl->Nlocs) {
             pl->nug_is_scalar = false;
             if (!pl->d_nug_user)
@@ -881,6 +890,94 @@ int gpv_plan_get_posterior_mean(gpv_plan *pl, double *mu_ord)
     GPV_HIP(hipSetDevice(pl->device));
     GPV_HIP(hipMemcpyAsync(mu_ord, pl->d_mu, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyDeviceToHost, pl->last_stream));
     GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    return GPV_OK;
+}
+
+// ---- Vecchia-Laplace Newton-Raphson on the device (R/vecchia_laplace_NR.R:31-155) -------------------------------
+int gpv_plan_vl_begin(gpv_plan *pl, int model, const double *likparms, const double *z_ord, const double *prior_mean_ord,
+                      const double *y_init_ord)
+{
+    if (!pl || !z_ord) return GPV_ERR_BAD_ARG;
+    if (!(model == 0 || model == 1 || model == 2 || model == 3 || model == 5)) return GPV_ERR_BAD_ARG;
+    if (!pl->have_post) return GPV_ERR_STATE;                       // every step is a posterior-mean evaluation
+    GPV_HIP(hipSetDevice(pl->device));
+    if (pl->last_stream && pl->last_stream != pl->stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    const size_t nb = sizeof(double) * (size_t)pl->Nlocs;
+    double **bufs[] = {&pl->d_vl_z, &pl->d_vl_pm, &pl->d_vl_y[0], &pl->d_vl_y[1], &pl->d_nug_user, &pl->d_zuser};
+    for (double **b : bufs)
+        if (!*b) GPV_HIP(hipMalloc((void **)b, nb));
+    if (pl->dim > 3 && !pl->d_z) GPV_HIP(hipMalloc((void **)&pl->d_z, nb));
+    if (!pl->d_vl_out) GPV_HIP(hipMalloc((void **)&pl->d_vl_out, sizeof(double) * 2));
+    if (!pl->d_vl_flags) GPV_HIP(hipMalloc((void **)&pl->d_vl_flags, sizeof(int)));
+    GPV_HIP(hipMemcpyAsync(pl->d_vl_z, z_ord, nb, hipMemcpyHostToDevice, pl->stream));
+    if (prior_mean_ord) GPV_HIP(hipMemcpyAsync(pl->d_vl_pm, prior_mean_ord, nb, hipMemcpyHostToDevice, pl->stream));
+    else GPV_HIP(hipMemsetAsync(pl->d_vl_pm, 0, nb, pl->stream));
+    // y_init NA -> prior mean (R/vecchia_laplace_NR.R:81-82)
+    if (y_init_ord) GPV_HIP(hipMemcpyAsync(pl->d_vl_y[0], y_init_ord, nb, hipMemcpyHostToDevice, pl->stream));
+    else GPV_HIP(hipMemcpyAsync(pl->d_vl_y[0], pl->d_vl_pm, nb, hipMemcpyDeviceToDevice, pl->stream));
+    GPV_HIP(hipStreamSynchronize(pl->stream));
+    pl->vl_model = model;
+    pl->vl_alpha = likparms ? likparms[0] : 2.0;
+    pl->vl_sigma = likparms ? likparms[1] : std::sqrt(0.1);
+    pl->vl_cur = 0;
+    pl->has_z = true;                                               // the pseudo-data of every step is the plan's data
+    return GPV_OK;
+}
+
+int gpv_plan_vl_step(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms, double *dmax, int *flags)
+{
+    if (!pl || !dmax || !flags) return GPV_ERR_BAD_ARG;
+    if (pl->vl_model < 0) return GPV_ERR_STATE;
+    CovSetup cs;
+    const int st0 = cov_setup(covType, covparms, ncovparms, cs);
+    if (st0 != GPV_OK) return st0;
+    GPV_HIP(hipSetDevice(pl->device));
+    hipStream_t st = pl->stream;
+    const double *y = pl->d_vl_y[pl->vl_cur];
+    double *ynew = pl->d_vl_y[pl->vl_cur ^ 1];
+    GPV_HIP(hipMemsetAsync(pl->d_vl_flags, 0, sizeof(int), st));
+    // pseudo-data and pseudo-nuggets of this step (:93-109) straight into the plan's data / nugget arrays
+    double *data_int = pl->dim <= 3 ? pl->d_locs : pl->d_z;
+    GPV_HIP(launch_vl_prepare(pl->vl_model, pl->vl_alpha, pl->vl_sigma, y, pl->d_vl_z, pl->d_vl_pm, pl->Nlocs, pl->d_newpos,
+                              data_int, pl->dim <= 3 ? 4 : 1, pl->dim <= 3 ? 3 : 0, pl->d_zuser, pl->d_nuggets, pl->d_nug_user,
+                              pl->d_vl_flags, st));
+    // vecchia_prediction(pseudo.data, nuggets = D, return.values = 'meanmat') (:112-113)
+    const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_MEAN, st, nullptr);
+    if (rc != GPV_OK) return rc;
+    GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, st));   // :115-117
+    double h_out = 0.0;
+    int h_flags = 0;
+    GPV_HIP(hipMemcpyAsync(&h_out, pl->d_vl_out, sizeof(double), hipMemcpyDeviceToHost, st));
+    GPV_HIP(hipMemcpyAsync(&h_flags, pl->d_vl_flags, sizeof(int), hipMemcpyDeviceToHost, st));
+    GPV_HIP(hipStreamSynchronize(st));
+    *dmax = h_out;
+    *flags = h_flags;
+    if (h_out == h_out) pl->vl_cur ^= 1;          // NaN: the reference keeps y_prev (:117-122)
+    return GPV_OK;
+}
+
+int gpv_plan_vl_get(gpv_plan *pl, double *mean_ord, double *t_ord, double *D_ord)
+{
+    // after >= 1 step: preds$mu.obs + prior_mean, pseudo.data + prior_mean and D of the LAST step, ordered layout (:141-144)
+    if (!pl) return GPV_ERR_BAD_ARG;
+    if (pl->vl_model < 0 || !pl->have_mean) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    const int64_t n = pl->Nlocs;
+    const size_t nb = sizeof(double) * (size_t)n;
+    std::vector<double> pm;
+    if (mean_ord || t_ord) {
+        pm.resize((size_t)n);
+        GPV_HIP(hipMemcpy(pm.data(), pl->d_vl_pm, nb, hipMemcpyDeviceToHost));
+    }
+    if (mean_ord) {
+        GPV_HIP(hipMemcpy(mean_ord, pl->d_mu, nb, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) mean_ord[i] += pm[(size_t)i];
+    }
+    if (t_ord) {
+        GPV_HIP(hipMemcpy(t_ord, pl->d_zuser, nb, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n; ++i) t_ord[i] += pm[(size_t)i];
+    }
+    if (D_ord) GPV_HIP(hipMemcpy(D_ord, pl->d_nug_user, nb, hipMemcpyDeviceToHost));
     return GPV_OK;
 }
 

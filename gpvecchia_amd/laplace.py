@@ -87,35 +87,95 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
 # ---------------------------------------------------------------------------
 # Newton-Raphson — R/vecchia_laplace_NR.R:31-155
 # ---------------------------------------------------------------------------
+_DEVICE_MODELS = {"gaussian": 0, "logistic": 1, "poisson": 2, "gamma": 3, "gamma_alt": 5}   # position in the list of :32
+
+
+def _posterior_VL_device(z, va, model, covparms, covmodel, likparms, max_iter, convg, y_init, prior_mean, fam, verbose, device):
+    """The loop of R/vecchia_laplace_NR.R:88-130 with y, z, the prior mean, the pseudo-data and the pseudo-nuggets resident
+    in HBM (gpv_plan_vl_begin / gpv_plan_vl_step): per step one elementwise family kernel, the plan's evaluation with vector
+    nuggets (set kernel + posterior pass + mean sweeps) and a max-norm; two scalars come back."""
+    import ctypes as C
+    from . import _lib as L
+    plan = A._plan_for(va, device)
+    if not plan.has_posterior:
+        plan.build_posterior()
+    ordz = va["ord_z"] - 1
+    lp = np.array([float(likparms.get("alpha", 2)), float(likparms.get("sigma", np.sqrt(.1)))])
+    zo = np.ascontiguousarray(z[ordz])
+    pmo = np.ascontiguousarray(prior_mean[ordz])
+    yo = np.ascontiguousarray(y_init[ordz])
+    L.check(L.lib().gpv_plan_vl_begin(plan._h, _DEVICE_MODELS[model], L.dptr(lp), L.dptr(zo), L.dptr(pmo), L.dptr(yo)),
+            "gpv_plan_vl_begin")
+    cp = np.ascontiguousarray(covparms, dtype=np.float64)
+    convgd, tot_iters = False, 0
+    dmax, flags = C.c_double(), C.c_int()
+    for i in range(1, max_iter + 1):                                      # :88
+        L.check(L.lib().gpv_plan_vl_step(plan._h, str(covmodel).encode(), L.dptr(cp), int(cp.size), C.byref(dmax),
+                                         C.byref(flags)), "gpv_plan_vl_step")
+        if flags.value & 1:
+            raise ValueError("Negative variances occurred, check parameters")   # :95-98
+        if flags.value & 2:
+            raise ValueError("Derivative of the loglikehood is infinite. Try different parameter values")   # :102
+        if np.isnan(dmax.value):                                          # :117-123
+            if verbose:
+                print(f"VL-NR hit NA on iteration {tot_iters}, convergence failed.")
+            break
+        if dmax.value < convg:                                            # :124-128
+            convgd, tot_iters = True, i
+            break
+        tot_iters += 1
+    n = len(z)
+    mean_o, t_o, D_o = np.empty(n), np.empty(n), np.empty(n)
+    L.check(L.lib().gpv_plan_vl_get(plan._h, L.dptr(mean_o), L.dptr(t_o), L.dptr(D_o)), "gpv_plan_vl_get")
+    mean, t, D = np.empty(n), np.empty(n), np.empty(n)
+    mean[ordz], t[ordz], D[ordz] = mean_o, t_o, D_o                       # back to the caller's order (:135-138)
+    preds = dict(mu_obs=mean - prior_mean, mu_pred=np.empty(0), var_obs=None, var_pred=None)
+    return dict(mean=mean, cnvgd=convgd, iter=tot_iters, t=t, D=D, prediction=preds, data_link=fam["link"],
+                model_llh=fam["llh"], prior_mean=prior_mean)
+
+
 def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covparms=None, covmodel="matern",
                            likparms=None, max_iter=50, convg=1e-6, y_init=None, prior_mean=None, verbose=False,
-                           device=0):
+                           device=0, on_device=None):
     z = np.asarray(z, dtype=np.float64)
     likparms = dict(alpha=2, sigma=np.sqrt(.1)) if likparms is None else dict(likparms)
     if covmodel == "matern" and len(covparms) != 3:
         raise ValueError(f"Matern kernel requires 3 parameters but {len(covparms)} were passed")   # :39-41
-    if np.any(np.isnan(z)):
-        raise NotImplementedError("missing observations in the VL loop are not built yet")
     fam = _families(likelihood_model, likparms)
-    if fam["bad"](z):
+    obs_inds = np.where(~np.isnan(z))[0]                                  # :45-46
+    z_obs = z[obs_inds]
+    if fam["bad"](z_obs):
         raise ValueError("Data invalid for likelihood type. Make sure that your data lies in the support of the "
                          "likelihood function.")                                                    # :52-54
     prior_mean = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64)
-    y_o = prior_mean.copy() if y_init is None or np.any(np.isnan(y_init)) else np.asarray(y_init, float).copy()   # :81-84
+    y_o = prior_mean.copy() if y_init is None or np.any(np.isnan(y_init)) else np.asarray(y_init, float).copy()   # :81-82
+    va = vecchia_approx
+    if (on_device is not False and likelihood_model in _DEVICE_MODELS and obs_inds.size == len(z) and isinstance(covmodel, str)
+            and va["cond_yz"] in ("SGV", "z") and int(np.sum(va["obs"])) == len(z)):
+        return _posterior_VL_device(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, y_o, prior_mean,
+                                    fam, verbose, device)
+    if on_device is True:
+        raise ValueError("on_device=True needs fully observed data, a family other than 'beta', cond.yz in {'SGV','z'}")
+    if len(y_o) > 1:
+        y_o = y_o[obs_inds]                                               # :84
+    pm_obs = prior_mean[obs_inds]
     convgd, tot_iters = False, 0
     pseudo, D, preds = None, None, None
     for i in range(1, max_iter + 1):                                      # :88
         y_prev = y_o
-        D_inv = fam["hess"](y_o, z)                                       # :93
+        D_inv = fam["hess"](y_o, z_obs)                                   # :93
         if np.any(D_inv < 0):
             raise ValueError("Negative variances occurred, check parameters")   # :95-98
         D = 1 / D_inv
-        u = fam["score"](y_o, z)
+        u = fam["score"](y_o, z_obs)
         if np.any(~np.isfinite(u)):
             raise ValueError("Derivative of the loglikehood is infinite. Try different parameter values")   # :102
-        pseudo = D * u + y_o - prior_mean                                 # :105
-        preds = vecchia_prediction(pseudo, vecchia_approx, covparms, D, covmodel, device=device)   # :112-113
-        y_o = preds["mu_obs"] + prior_mean                                # :115
+        pseudo = np.full(len(z), np.nan)                                  # :103
+        pseudo[obs_inds] = D * u + y_o - pm_obs                           # :105
+        nuggets = np.full(len(z), np.inf)                                 # :107-108: unobserved locations carry no information
+        nuggets[obs_inds] = D                                             #   (removeNAs of vecchia_prediction then replaces the
+        preds = vecchia_prediction(pseudo, vecchia_approx, covparms, nuggets, covmodel, device=device)   # NA data, :112-113)
+        y_o = preds["mu_obs"][obs_inds] + pm_obs                          # :115
         dmax = np.max(np.abs(y_o - y_prev))
         if np.isnan(dmax):                                                # :117-123
             if verbose:
@@ -127,7 +187,7 @@ def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covpa
             break
         tot_iters += 1
     return dict(mean=preds["mu_obs"] + prior_mean, cnvgd=convgd, iter=tot_iters, t=pseudo + prior_mean, D=D,
-                prediction=preds, data_link=fam["link"], model_llh=fam["llh"], prior_mean=prior_mean)
+                prediction=preds, data_link=fam["link"], model_llh=fam["llh"], prior_mean=prior_mean)   # :141-144
 
 
 # ---------------------------------------------------------------------------
@@ -138,13 +198,20 @@ def vecchia_laplace_likelihood_from_posterior(z, posterior, vecchia_approx, like
     """R/vecchia_laplace_NR.R:444-491: the three log-likelihood terms from an existing calculate_posterior_VL result."""
     z = np.asarray(z, dtype=np.float64)
     pm = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64)
-    z_pseudo = posterior["t"] - pm                                        # :455
-    nug_pseudo = posterior["D"]
-    pseudo_marginal = A.vecchia_likelihood(z_pseudo, vecchia_approx, covparms, nug_pseudo, covmodel, device=device)   # :470-471
-    true_llh = posterior["model_llh"](posterior["mean"], z)               # :475-476
+    z_pseudo = posterior["t"] - pm                                        # :381 / :455
+    nug_pseudo = np.asarray(posterior["D"], dtype=np.float64)
+    if nug_pseudo.size < z_pseudo.size and np.any(np.isnan(z_pseudo)):    # :382-387 missing observations
+        full = np.full(z_pseudo.size, np.nan)
+        full[~np.isnan(z_pseudo)] = nug_pseudo
+        nug_pseudo = full
+    # vecchia_likelihood's removeNAs gives the missing entries the mean and a nugget of var * 1e8 (R/vecchia_likelihood.R:45-58)
+    pseudo_marginal = A.vecchia_likelihood(z_pseudo, vecchia_approx, covparms, nug_pseudo, covmodel, device=device)   # :396-397
+    ind_obs = ~np.isnan(z)                                                # :401
+    true_llh = posterior["model_llh"](posterior["mean"][ind_obs], z[ind_obs])   # :402
     m = posterior["mean"] - pm
-    pseudo_cond = np.sum(-0.5 * np.log(2 * np.pi * nug_pseudo) - 0.5 * (z_pseudo - m) ** 2 / nug_pseudo)   # :479 dnorm(log=TRUE)
-    ll = pseudo_marginal - pseudo_cond + true_llh                         # :482-483
+    with np.errstate(invalid="ignore"):
+        pseudo_cond = np.nansum(-0.5 * np.log(2 * np.pi * nug_pseudo) - 0.5 * (z_pseudo - m) ** 2 / nug_pseudo)   # :405 dnorm(log=TRUE), na.rm
+    ll = pseudo_marginal - pseudo_cond + true_llh                         # :408-409
     if y_init is None:
         return ll
     return dict(llv=ll, mean=posterior["mean"])

@@ -170,6 +170,23 @@ int gpv_plan_posterior_levels(gpv_plan *plan, int *n_levels);
 /* blocking: mu.ord (length Nlocs, ordered layout) after an eval with GPV_WANT_MEAN */
 int gpv_plan_get_posterior_mean(gpv_plan *plan, double *mu_ord);
 
+/* Vecchia-Laplace Newton-Raphson with the state on the device: calculate_posterior_VL of R/vecchia_laplace_NR.R:31-155
+ * for fully observed data.  model: position in the reference's family list (:32): 0 gaussian, 1 logistic, 2 poisson,
+ * 3 gamma, 5 gamma_alt (4 = beta needs digamma: host path of the caller).  likparms = {alpha, sigma} (:33).
+ * z_ord / prior_mean_ord / y_init_ord: ORDERED layout, length Nlocs; prior_mean_ord NULL = 0, y_init_ord NULL = prior
+ * mean (:81-82).  Needs gpv_plan_build_posterior.
+ * One gpv_plan_vl_step = one pass of the loop body (:91-129): Hessian/score of the family, pseudo-data and
+ * pseudo-nuggets (elementwise kernel), then the plan's ordinary evaluation with GPV_WANT_MEAN (U_NZentries with vector
+ * nuggets, U2V, vecchia_mean) and y <- mu + prior_mean.  Returns *dmax = max|y_new - y_prev| (NaN if any entry is NaN:
+ * the reference then stops and keeps y_prev) and *flags: bit 0 = a negative Hessian occurred (the reference stops with
+ * "Negative variances occurred", :95-98), bit 1 = a non-finite score (:102).  Blocking; only these scalars cross PCIe. */
+int gpv_plan_vl_begin(gpv_plan *plan, int model, const double *likparms, const double *z_ord,
+                      const double *prior_mean_ord, const double *y_init_ord);
+int gpv_plan_vl_step(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms, double *dmax, int *flags);
+/* results of the last step in ordered layout (any pointer may be NULL): posterior mean mu.obs + prior_mean,
+ * t = pseudo.data + prior_mean, D (:141-144) */
+int gpv_plan_vl_get(gpv_plan *plan, double *mean_ord, double *t_ord, double *D_ord);
+
 /* blocking getters (synchronise the eval's stream first) */
 int gpv_plan_get_sums(gpv_plan *plan, double *sums /* GPV_NSUMS */);
 int gpv_plan_get_Lentries(gpv_plan *plan, double *Lentries /* (row_end-row_begin) x ncolNN col-major */);

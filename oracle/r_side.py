@@ -504,8 +504,24 @@ def vecchia_likelihood_U(z, U_obj):
     return -neg2loglik / 2                                          # :96
 
 
+def removeNAs(z, nuggets):
+    """R/vecchia_likelihood.R:45-58: missing data get the mean of the rest and a nugget of var * 1e8 (stats::var: n-1)."""
+    z = np.array(z, dtype=np.float64)
+    nug = np.atleast_1d(np.array(nuggets, dtype=np.float64))
+    na = np.isnan(z)
+    if na.any():                                                        # :47
+        if nug.size < z.size:                                           # :49-53
+            new = np.zeros(z.size)
+            new[~na] = nug
+            nug = new
+        nug[na] = np.var(z[~na], ddof=1) * 1e8                          # :55
+        z[na] = np.mean(z[~na])                                         # :56
+    return z, nug
+
+
 def vecchia_likelihood(z, va, covparms, nuggets, covmodel="matern"):
-    """R/vecchia_likelihood.R:14-27 (without the NA handling of removeNAs)."""
+    """R/vecchia_likelihood.R:14-27."""
+    z, nuggets = removeNAs(z, nuggets)                                  # :20
     return vecchia_likelihood_U(z, createU(va, covparms, nuggets, covmodel))
 
 
@@ -561,6 +577,7 @@ def vecchia_mean(z, U_obj, V):
 
 def vecchia_prediction_mean(z, va, covparms, nuggets, covmodel="matern"):
     """R/vecchia_prediction.R:17-56 with return.values='meanmat' (mean only)."""
+    z, nuggets = removeNAs(z, nuggets)                                 # :22
     U_obj = createU(va, covparms, nuggets, covmodel)                   # :25
     V = U2V(U_obj)                                                     # :28
     return vecchia_mean(z, U_obj, V)                                   # :34
@@ -589,19 +606,26 @@ def vl_family(model, likparms=None):
 
 def calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel="matern", likparms=None, max_iter=50,
                            convg=1e-6, prior_mean=None):
-    """R/vecchia_laplace_NR.R:31-155 (no missing data)."""
+    """R/vecchia_laplace_NR.R:31-155, missing observations (NaN in z) included."""
     z = np.asarray(z, dtype=np.float64)
     fam = vl_family(likelihood_model, likparms)
     pm = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, float)
+    obs = np.where(~np.isnan(z))[0]                                    # :45
+    z_obs = z[obs]
     y_o = pm.copy()                                                    # :81-82
+    if len(y_o) > 1:
+        y_o = y_o[obs]                                                 # :84
     convgd, tot = False, 0
     for i in range(1, max_iter + 1):                                   # :88
         y_prev = y_o
-        D = 1 / fam["hess"](y_o, z)                                    # :93,100
-        u = fam["score"](y_o, z)                                       # :101
-        pseudo = D * u + y_o - pm                                      # :105
-        mu = vecchia_prediction_mean(pseudo, va, covparms, D, covmodel)    # :112-113
-        y_o = mu + pm                                                  # :115
+        D = 1 / fam["hess"](y_o, z_obs)                                # :93,100
+        u = fam["score"](y_o, z_obs)                                   # :101
+        pseudo = np.full(len(z), np.nan)                               # :103
+        pseudo[obs] = D * u + y_o - pm[obs]                            # :105
+        nuggets = np.full(len(z), np.inf)                              # :107
+        nuggets[obs] = D                                               # :108
+        mu = vecchia_prediction_mean(pseudo, va, covparms, nuggets, covmodel)    # :112-113
+        y_o = mu[obs] + pm[obs]                                        # :115
         if np.max(np.abs(y_o - y_prev)) < convg:                       # :124
             convgd, tot = True, i
             break
@@ -619,7 +643,13 @@ def vecchia_laplace_likelihood(z, va, likelihood_model, covparms, likparms=None,
     pm = post["prior_mean"]
     z_pseudo = post["t"] - pm                                          # :381
     D = post["D"]
+    if len(D) < len(z_pseudo) and np.any(np.isnan(z_pseudo)):          # :382-387
+        full = np.full(len(z_pseudo), np.nan)
+        full[~np.isnan(z_pseudo)] = D
+        D = full
     marg = vecchia_likelihood(z_pseudo, va, covparms, D, covmodel)     # :396-397
-    true_llh = post["model_llh"](post["mean"], z)                      # :402
-    cond = np.sum(-0.5 * np.log(2 * np.pi * D) - 0.5 * (z_pseudo - (post["mean"] - pm)) ** 2 / D)   # :405
+    io = ~np.isnan(z)                                                  # :401
+    true_llh = post["model_llh"](post["mean"][io], z[io])              # :402
+    with np.errstate(invalid="ignore"):
+        cond = np.nansum(-0.5 * np.log(2 * np.pi * D) - 0.5 * (z_pseudo - (post["mean"] - pm)) ** 2 / D)   # :405, na.rm
     return marg - cond + true_llh                                      # :408-409

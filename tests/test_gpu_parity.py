@@ -627,6 +627,67 @@ def test_vecchia_laplace_likelihood(model):
         G.calculate_posterior_VL(np.full(n, -1.0), va, "poisson", cp)      # data outside the support (:52-54)
 
 
+@pytest.mark.parametrize("model", ["poisson", "logistic", "gamma", "gamma_alt", "gaussian"])
+def test_vecchia_laplace_device_loop_equals_host_loop(model):
+    # gpv_plan_vl_begin/step (family arithmetic, pseudo-data and the convergence norm on the device) against the same
+    # loop with the family functions in NumPy and one vecchia_prediction per step (the round-1 path, on_device=False)
+    G = _need_gpu()
+    rng = np.random.default_rng(77)
+    n, m = 3000, 15
+    locs = rng.random((n, 2))
+    f = 0.7 * np.sin(6 * locs[:, 0]) * np.cos(5 * locs[:, 1])
+    cp = [0.5, 0.1, 1.5]
+    if model == "poisson":
+        z = rng.poisson(np.exp(f)).astype(float)
+    elif model == "logistic":
+        z = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
+    elif model == "gamma":
+        z = rng.gamma(2.0, np.exp(f) / 2.0)
+    elif model == "gamma_alt":
+        z = rng.gamma(2.0, 1.0 / np.exp(f))
+    else:
+        z = f + np.sqrt(.1) * rng.standard_normal(n)
+    pm = 0.1 * np.cos(3 * locs[:, 0])                                   # a non-trivial prior mean
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    host = G.calculate_posterior_VL(z, va, model, cp, prior_mean=pm, on_device=False)
+    dev = G.calculate_posterior_VL(z, va, model, cp, prior_mean=pm, on_device=True)
+    assert dev["cnvgd"] and host["cnvgd"] and dev["iter"] == host["iter"]
+    np.testing.assert_allclose(dev["mean"], host["mean"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(dev["t"], host["t"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(dev["D"], host["D"], rtol=1e-12)
+    ll_h = G.vecchia_laplace_likelihood_from_posterior(z, host, va, model, cp, prior_mean=pm)
+    ll_d = G.vecchia_laplace_likelihood_from_posterior(z, dev, va, model, cp, prior_mean=pm)
+    assert abs(ll_d - ll_h) <= 1e-10 * abs(ll_h)
+    # the stopping rules of the reference: data outside the support, negative Hessian
+    if model == "gamma":
+        with pytest.raises(ValueError):
+            G.calculate_posterior_VL(-z, va, model, cp)                 # support check (:52-54)
+
+
+def test_vecchia_laplace_missing_observations():
+    # R/vecchia_laplace_NR.R:45-46,84,103-108: NA data are skipped by the family functions, carry an Inf pseudo-nugget,
+    # and vecchia_prediction's removeNAs turns them into mean / var*1e8 (R/vecchia_likelihood.R:45-58)
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(23)
+    n, m = 600, 10
+    locs = rng.random((n, 2))
+    cp = [0.6, 0.15, 1.5]
+    y = np.linalg.cholesky(R.MaternFun(R.rdist(locs), cp) + 1e-10 * np.eye(n)) @ rng.standard_normal(n)
+    z = rng.poisson(np.exp(y)).astype(float)
+    z[rng.choice(n, 70, replace=False)] = np.nan
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    post_ref = R.calculate_posterior_VL(z, vb, "poisson", cp)
+    ll_ref = R.vecchia_laplace_likelihood(z, vb, "poisson", cp)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    post = G.calculate_posterior_VL(z, va, "poisson", cp)
+    assert post["cnvgd"] and post_ref["cnvgd"] and post["iter"] == post_ref["iter"]
+    assert len(post["D"]) == n - 70 and np.isnan(post["t"]).sum() == 70
+    np.testing.assert_allclose(post["mean"], post_ref["mean"], rtol=0, atol=1e-7)
+    ll = G.vecchia_laplace_likelihood(z, va, "poisson", cp)
+    assert abs(ll - ll_ref) <= 1e-7 * abs(ll_ref)
+
+
 @pytest.mark.parametrize("n,m,d", [(700, 10, 2), (3000, 30, 2), (1500, 7, 1), (1200, 20, 3), (900, 12, 5), (40, 60, 2)])
 def test_gpu_ordered_nn_bit_exact(n, m, d):
     # north-star: neighbour index arrays bit-exact.  GPU brute force vs the oracle's literal findOrderedNN

@@ -31,12 +31,16 @@ t0 = time.time()
 post = G.calculate_posterior_VL(z, va, "poisson", cp)
 t_first = time.time() - t0                                                 # includes plan upload + posterior structure
 t0 = time.time()
-post = G.calculate_posterior_VL(z, va, "poisson", cp)
+post = G.calculate_posterior_VL(z, va, "poisson", cp)                      # device loop (gpv_plan_vl_step)
 t_nr = time.time() - t0
+t0 = time.time()
+post_h = G.calculate_posterior_VL(z, va, "poisson", cp, on_device=False)   # family arithmetic in NumPy, data over PCIe every step
+t_nr_host = time.time() - t0
 t0 = time.time()
 ll = G.vecchia_laplace_likelihood(z, va, "poisson", cp)
 t_ll = time.time() - t0
 print(json.dumps({"n": a.n, "m": a.m, "specify_s": round(t_spec, 2), "first_posterior_s": round(t_first, 2),
                   "nr_loop_s": round(t_nr, 3), "nr_iters": post["iter"], "converged": bool(post["cnvgd"]),
-                  "ms_per_nr_iter": round(1e3 * t_nr / max(post["iter"], 1), 2), "laplace_loglik_s": round(t_ll, 3),
+                  "ms_per_nr_iter": round(1e3 * t_nr / max(post["iter"], 1), 2),
+                  "ms_per_nr_iter_host_loop": round(1e3 * t_nr_host / max(post_h["iter"], 1), 2), "laplace_loglik_s": round(t_ll, 3),
                   "loglik": ll, "rmse_latent": float(np.sqrt(np.mean((post["mean"] - y) ** 2)))}))
