@@ -257,28 +257,33 @@ def EsqeFun(distmat, covparms):
 # ---------------------------------------------------------------------------
 def vecchia_specify(locs, m=-1, ordering=None, cond_yz=None, locs_pred=None, ordering_pred=None, pred_cond=None,
                     conditioning=None, mra_options=None, ic0=False, verbose=False, NNarray=None, nn_backend="auto"):
-    """Parameter-independent specification of the Vecchia approximation.
-
-    Implemented: no prediction locations, conditioning='NN', ordering in
-    {'coord','maxmin','outsidein','none'}, cond.yz in {'SGV','y','z'} and the m=0
-    independent case.  Prediction locations, 'zy'/'RVP'/'LK' and MRA conditioning
-    feed the same hot path but are not built yet (NotImplementedError)."""
+    """Parameter-independent specification of the Vecchia approximation, conditioning='NN':
+    ordering in {'coord','maxmin','outsidein','none'}; cond.yz in {'SGV','SGVT','y','z','zy','RVP','LK'}; prediction
+    locations with ordering.pred in {'obspred','general'} and pred.cond in {'general','independent'}; the m = 0
+    independent case.  MRA / 'firstm' conditioning goes through ic0 in the reference, never through U_NZentries
+    (R/createU.R:89): not built (NotImplementedError)."""
     locs = np.asarray(locs, dtype=np.float64)
     if locs.ndim != 2:
         warnings.warn("Locations must be in matrix form")                    # :32-35
         return None
     if m is None or m == -1:
         raise ValueError("neither m nor r defined!")                        # :36-40
-    if locs_pred is not None:
-        raise NotImplementedError("prediction locations are outside the round-1 hot-path scope")
     if conditioning not in (None, "NN"):
         raise NotImplementedError("conditioning='mra'/'firstm' goes through ic0, not U_NZentries (R/createU.R:89)")
     spatial_dim = locs.shape[1]
     n = locs.shape[0]
+    have_pred = locs_pred is not None
+    if have_pred:                                                            # :46-51
+        locs_pred = np.asarray(locs_pred, dtype=np.float64).reshape(-1, spatial_dim)
+        la = np.vstack([locs, locs_pred])
+        if np.unique(la, axis=0).shape[0] < la.shape[0]:
+            raise ValueError("Prediction locations contain observed location(s), remove redundancies.")
     if m > n:                                                                # :53-56
         warnings.warn("Conditioning set size m chosen to be larger than n. Changing to m=n-1")
         m = n - 1
     if m == 0:                                                               # :59-73
+        if have_pred:
+            warnings.warn("Attempting to make predictions with m=0.  Prediction ignored")
         ord_ = np.arange(1, n + 1)
         NN = np.stack([ord_, np.zeros(n, dtype=np.int64)], axis=1).astype(np.int32)
         Cond = np.stack([np.ones(n), -np.ones(n)], axis=1).astype(np.int8)
@@ -288,41 +293,111 @@ def vecchia_specify(locs, m=-1, ordering=None, cond_yz=None, locs_pred=None, ord
                     cond_yz="false", conditioning="NN", ic0=False)
     if ordering is None:                                                     # :83-85
         ordering = "coord" if spatial_dim == 1 else "maxmin"
+    if pred_cond is None:                                                    # :86
+        pred_cond = "general"
     if cond_yz is None:                                                      # :92-96
-        cond_yz = "SGV"
-    if ordering == "coord":                                                  # :102
-        ord_ = S.order_coordinate(locs)
-    elif ordering == "maxmin":                                               # :103-106
-        o = S.order_maxmin_exact(locs)
-        cut = min(n, 9)
-        ord_ = np.concatenate([o[:1], o[cut:], o[1:cut]])
-    elif ordering == "outsidein":                                            # :107-108
-        ord_ = S.order_outsidein(locs)
-    elif ordering == "none":                                                 # :109-110
-        ord_ = np.arange(1, n + 1)
-    else:
+        cond_yz = "SGV" if (not have_pred or spatial_dim == 1) else "zy"
+    if ordering not in ("coord", "maxmin", "outsidein", "none"):
         raise ValueError(f"ordering='{ordering}' not defined")
-    locsord = locs[ord_ - 1]
-    obs = np.ones(n, dtype=bool)
+    n_p = 0
+    if not have_pred:                                                        # :100-117
+        if ordering == "coord":                                              # :102
+            ord_ = S.order_coordinate(locs)
+        elif ordering == "maxmin":                                           # :103-106
+            o = S.order_maxmin_exact(locs)
+            cut = min(n, 9)
+            ord_ = np.concatenate([o[:1], o[cut:], o[1:cut]])
+        elif ordering == "outsidein":                                        # :107-108
+            ord_ = S.order_outsidein(locs)
+        else:                                                                # :109-110
+            ord_ = np.arange(1, n + 1)
+        ord_z = ord_.copy()
+        locsord = locs[ord_ - 1]
+        obs = np.ones(n, dtype=bool)
+        ordering_pred = "general"
+    else:                                                                    # :119-149 prediction is desired
+        n_p = locs_pred.shape[0]
+        locs_all = np.vstack([locs, locs_pred])
+        observed_obspred = np.concatenate([np.ones(n, bool), np.zeros(n_p, bool)])
+        if ordering_pred is None:                                            # :124-126
+            ordering_pred = "general" if (spatial_dim == 1 and ordering == "coord") else "obspred"
+        if ordering_pred == "general":                                       # :127-131
+            ord_ = S.order_coordinate(locs_all) if ordering == "coord" else S.order_maxmin_exact(locs_all)
+            ord_obs = ord_[ord_ <= n]
+        else:                                                                # :132-145
+            if ordering == "coord":
+                ord_obs, ord_pr = S.order_coordinate(locs), S.order_coordinate(locs_pred)
+            elif ordering == "none":
+                ord_obs, ord_pr = np.arange(1, n + 1), np.arange(1, n_p + 1)
+            else:
+                ord_obs, ord_pr = S.order_maxmin_exact_obs_pred(locs, locs_pred)
+            ord_ = np.concatenate([ord_obs, ord_pr + n])
+        ord_z = ord_obs
+        locsord = locs_all[ord_ - 1]
+        obs = observed_obspred[ord_ - 1]
+    nall = locsord.shape[0]
     if NNarray is None:                                                      # :157-159
         # both searches implement the same exact definition and return identical arrays (tests); "gpu" is the
         # library's brute-force kernel, "host" the cKDTree search
-        use_gpu = nn_backend == "gpu" or (nn_backend == "auto" and L.device_count() > 0 and n >= 2000)
+        use_gpu = nn_backend == "gpu" or (nn_backend == "auto" and L.device_count() > 0 and nall >= 2000)
         NNarray = S.find_ordered_nn_gpu(locsord, m) if use_gpu else S.find_ordered_nn(locsord, m)
     NNarray = np.asarray(NNarray).astype(np.int32)
+    if have_pred and pred_cond == "independent":                             # :168-178
+        if ordering_pred == "obspred":
+            # every prediction location conditions on itself and its m nearest OBSERVED locations, descending index
+            from scipy.spatial import cKDTree
+            _, idx = cKDTree(locsord[:n]).query(locsord[n:], k=m)
+            idx = np.sort(idx.reshape(n_p, m) + 1, axis=1)[:, ::-1]
+            NNarray = NNarray.copy()
+            NNarray[n:] = np.concatenate([(n + np.arange(1, n_p + 1))[:, None], idx], axis=1)
+        else:
+            warnings.warn("indep. conditioning currently only implemented for obspred ordering")
     if cond_yz == "SGV":                                                     # :182-183
         Cond = S.whichCondOnLatent(NNarray, firstind_pred=n + 1)
+    elif cond_yz == "SGVT":                                                  # :184-185
+        Cond = np.vstack([S.whichCondOnLatent(NNarray[:n]), np.ones((n_p, m + 1), dtype=np.int8)])
     elif cond_yz == "y":                                                     # :186-187
         Cond = np.where(NNarray != 0, 1, -1).astype(np.int8)
     elif cond_yz == "z":                                                     # :189-190
+        if have_pred:
+            raise ValueError("cond.yz='z' cannot be combined with prediction locations (an unobserved location has no z "
+                             "to condition on; the reference fails in U_sparsity)")
         Cond = np.where(NNarray != 0, 0, -1).astype(np.int8)
         Cond[:, 0] = 1
-    elif cond_yz in ("RVP", "LK", "zy", "SGVT"):
-        raise NotImplementedError(f"cond.yz='{cond_yz}' is not built yet")
+    elif cond_yz in ("RVP", "LK", "zy"):                                     # :191-223 response-latent ('zy') trick
+        obs = np.concatenate([np.ones(n, bool), np.zeros(nall, bool)])       # :195
+        locsord = np.vstack([locsord[:n], locsord])                          # :196
+        NNs = S.get_knn(locsord[:n], m - 1).astype(np.int64)                 # :199
+        if cond_yz in ("RVP", "zy"):                                         # :200-203 latent y.obs where it comes earlier
+            prev = NNs < np.arange(1, n + 1)[:, None]
+            NNs[prev] += n
+        NN_z = np.concatenate([np.arange(1, n + 1)[:, None], np.zeros((n, m), dtype=np.int64)], axis=1)       # :206
+        NN_y = np.concatenate([(np.arange(1, n + 1) + n)[:, None], np.arange(1, n + 1)[:, None], NNs], axis=1)   # :207
+        if not have_pred:                                                    # :208-210
+            NN_yp = np.zeros((0, m + 1), dtype=np.int64)
+            ordering_pred = "obspred"
+        else:
+            if ordering_pred != "obspred":
+                warnings.warn("ZY only implemented for obspred ordering")
+            NN_yp = NNarray[n: n + n_p].astype(np.int64)
+            if cond_yz == "zy":                                              # :213-214
+                NN_yp = np.where(NN_yp != 0, NN_yp + n, 0)
+            else:                                                            # :215-218
+                NN_yp = np.where(NN_yp > n, NN_yp + n, NN_yp)
+        NNarray = np.vstack([NN_z, NN_y, NN_yp]).astype(np.int32)            # :220
+        Cond = np.where(NNarray == 0, -1, (NNarray > n).astype(np.int8)).astype(np.int8)   # :223
+        Cond[:, 0] = 1
+        cond_yz = "zy"
     else:
         raise ValueError(f"cond.yz='{cond_yz}' not defined")                 # :226
+    # a neighbour conditioned on as an observation must have one: the reference would put NA indices into sparseMatrix
+    # (R/U_sparsity.R:52) and fail in createU; e.g. cond.yz='SGV' with ordering.pred='general' in two dimensions
+    nb = np.where(NNarray > 0, NNarray - 1, 0)
+    if np.any((Cond == 0) & (NNarray > 0) & ~np.asarray(obs)[nb]):
+        raise ValueError(f"cond.yz='{cond_yz}' with ordering.pred='{ordering_pred}' conditions on the observation of an "
+                         "unobserved location; use ordering.pred='obspred' or cond.yz in {'y','zy'}")
     U_prep = S.U_sparsity(locsord, NNarray, obs, Cond)                       # :230
-    return dict(locsord=locsord, obs=obs, ord=ord_, ord_z=ord_.copy(), ord_pred="general", U_prep=U_prep,
+    return dict(locsord=locsord, obs=obs, ord=ord_, ord_z=ord_z, ord_pred=ordering_pred, U_prep=U_prep,
                 cond_yz=cond_yz, ic0=ic0, conditioning="NN")                 # :234-235
 
 
@@ -344,11 +419,15 @@ def _device_nuggets(va, nug):
 
 
 def _ordered_nuggets(va, nuggets, n):
-    """R/createU.R:73-78 for the all-observed, non-'zy' case."""
+    """R/createU.R:73-78: (nuggets.all.ord for every row of locsord, nuggets.ord for the observations, nuggets)."""
     nug = np.atleast_1d(np.asarray(nuggets, dtype=np.float64))
     if nug.size == 1:
-        nug = np.repeat(nug, n)
-    return nug[va["ord"] - 1], nug[va["ord_z"] - 1], nug
+        nug = np.repeat(nug, n)                                               # :74
+    nlat = va["locsord"].shape[0]                                            # = sum(latent)
+    nug_all = np.concatenate([nug, np.zeros(nlat - n)])                      # :75 prediction / dummy locations carry none
+    ord_ = va["ord"]
+    ord_all = np.concatenate([ord_[:n], ord_ + n]) if va["cond_yz"] == "zy" else ord_   # :76
+    return nug_all[ord_all - 1], nug_all[va["ord_z"] - 1], nug
 
 
 # ---------------------------------------------------------------------------
@@ -369,8 +448,9 @@ def createU(vecchia_approx, covparms, nuggets, covmodel="matern", device=0):
         zero_idx = np.where(nug_ord == 0)[0] + 1
         revCond = revCond.copy()
         revCond[np.isin(revNN, zero_idx)] = 1
+    plain = (n == va["locsord"].shape[0]) and va["cond_yz"] != "zy"          # every row observed: the resident plan serves
     if isinstance(covmodel, str):                                            # :152-154
-        if np.any(nug == 0):
+        if np.any(nug == 0) or not plain:
             ent = U_NZentries(prep["n_cores"], n, va["locsord"], revNN, revCond, nug_all_ord, nug_ord, covmodel,
                               covparms)
             Lent, Zent = ent["Lentries"], ent["Zentries"]
@@ -391,6 +471,13 @@ def createU(vecchia_approx, covparms, nuggets, covmodel="matern", device=0):
     vals = np.concatenate([np.ascontiguousarray(Lent)[keep], Zent])
     U = sp.csc_matrix((vals, (prep["colindices"] - 1, prep["rowpointers"] - 1)), shape=(size, size))   # :161-162
     ord_, obs, zero_nugg = va["ord"], va["obs"], {}
+    if va["cond_yz"] == "zy":                                                # :166-171 rows/columns of the dummy y's
+        keepd = np.ones(size, dtype=bool)
+        keepd[2 * np.arange(n)] = False                                      # dummy = 2*(1:n)-1 (1-based)
+        U = U.tocsr()[keepd][:, keepd].tocsc()
+        latent = latent[keepd]
+        obs = np.delete(obs, np.arange(n, 2 * n))
+        size = int(keepd.sum())
     if np.any(nug == 0):                                                     # :173-193
         # rows/columns of observations with zero noise are removed; the latent variable they pin down
         # takes their place as an "observed" row
@@ -446,21 +533,56 @@ def ichol_lower(Wrev):
     return sp.csr_matrix((vals, inds, ptrs), shape=Lw.shape)
 
 
+def _chol_rev(A, ic0):
+    """t(chol(revMat(A))) as a sparse lower-triangular matrix (R/vecchia_prediction.R:74-81): SuperLU without pivoting in
+    the natural order is L D L^T, the Cholesky factor is L sqrt(D); with ic0 the zero-fill factor of src/ic0.cpp."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    nA = A.shape[0]
+    rev = np.arange(nA - 1, -1, -1)
+    Arev = A.tocsr()[rev][:, rev].tocsc()
+    if ic0:
+        return ichol_lower(Arev)
+    lu = spla.splu(Arev, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    if not (np.array_equal(lu.perm_r, np.arange(nA)) and np.array_equal(lu.perm_c, np.arange(nA))):
+        raise RuntimeError("U2V: the sparse factorisation pivoted (matrix not positive definite?)")
+    d = lu.U.diagonal()
+    return (lu.L @ sp.diags(np.sqrt(d))).tocsr()
+
+
 def U2V(U_obj):
-    """R/vecchia_prediction.R:62-83 (non-'zy', general ordering): V = t(chol(rev(U_y U_y^T))).
-    Host-side (the reference runs CHOLMOD here; sequential sparse factorisation).
-    Returned as a SuperLU factor object of W.rev usable for logdet and solves."""
+    """R/vecchia_prediction.R:62-111.  Host-side like the reference (CHOLMOD there; sequential sparse factorisation,
+    SURVEY §8f-1).  Returns an object with `solve` = (V V^T)^{-1} and `U.diagonal()` = diag(V)^2:
+      * general ordering, non-'zy': a SuperLU factor of W.rev = rev(U_y U_y^T) (or the IC(0) factor with ic0 = TRUE, :76-77);
+      * 'zy': V.ord is the reversed latent block of U itself, no factorisation (:68-70);
+      * obs-pred ordering: prediction columns of U_y unchanged, Cholesky of the observed block only (:85-107)."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
     U = U_obj["U"].tocsr()
-    Uy = U[np.where(U_obj["latent"])[0], :]
-    W = (Uy @ Uy.T).tocsc()
-    nW = W.shape[0]
-    rev = np.arange(nW - 1, -1, -1)
-    Wrev = W[rev][:, rev].tocsc()
-    if U_obj.get("ic0", False):                                             # R/vecchia_prediction.R:76-77
-        return _TriFactor(ichol_lower(Wrev))
-    return spla.splu(Wrev, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    latent = U_obj["latent"]
+    lat_idx = np.where(latent)[0]
+    Uy = U[lat_idx, :]
+    if U_obj.get("cond_yz") == "zy":                                        # :68-70
+        B = Uy[:, lat_idx]
+        r = np.arange(B.shape[0] - 1, -1, -1)
+        return _TriFactor(B[r][:, r].tocsr())
+    if U_obj.get("ord_pred", "general") != "obspred":                       # :72-83
+        W = (Uy @ Uy.T).tocsc()
+        nW = W.shape[0]
+        rev = np.arange(nW - 1, -1, -1)
+        Wrev = W[rev][:, rev].tocsc()
+        if U_obj.get("ic0", False):                                         # :76-77
+            return _TriFactor(ichol_lower(Wrev))
+        return spla.splu(Wrev, permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    last_obs = int(np.max(np.where(~latent)[0])) + 1                        # :87
+    lat_before = int(latent[:last_obs].sum())                               # :88
+    lat_after = int(latent[last_obs:].sum())                                # :89
+    Vpr = Uy[:, last_obs:]
+    Vpr = Vpr[np.arange(Vpr.shape[0] - 1, -1, -1)][:, np.arange(Vpr.shape[1] - 1, -1, -1)]   # :92 revMat
+    Uoo = Uy[:lat_before, :last_obs]                                        # :95
+    Voor = _chol_rev((Uoo @ Uoo.T).tocsc(), U_obj.get("ic0", False))        # :96-100
+    Vor = sp.vstack([sp.csr_matrix((lat_after, lat_before)), Voor])         # :103-104
+    return _TriFactor(sp.hstack([Vpr, Vor]).tocsr())                        # :106
 
 
 class _TriFactor:
@@ -483,7 +605,7 @@ class _TriFactor:
 
 
 def vecchia_mean_host(z, U_obj):
-    """R/vecchia_prediction.R:118-126 on the host (sparse LU of W.rev): mu.ord = -W^{-1} z2."""
+    """R/vecchia_prediction.R:118-126 on the host: mu.ord = -W^{-1} z2 (ordered layout, one entry per latent variable)."""
     U = U_obj["U"].tocsr()
     latent = U_obj["latent"]
     zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]
@@ -491,6 +613,14 @@ def vecchia_mean_host(z, U_obj):
     z2 = U[np.where(latent)[0], :] @ z1
     lu = U2V(U_obj)
     return -(lu.solve(z2[::-1]))[::-1]
+
+
+def split_mean(mu_ord, U_obj):
+    """R/vecchia_prediction.R:134-139: ordered posterior mean -> (mu.obs, mu.pred) in the caller's order."""
+    orig_order = np.argsort(U_obj["ord"], kind="stable")
+    mu = np.asarray(mu_ord)[orig_order]
+    obs_orig = np.asarray(U_obj["obs"], dtype=bool)[orig_order]
+    return mu[obs_orig], mu[~obs_orig]
 
 
 def vecchia_likelihood_U(z, U_obj):

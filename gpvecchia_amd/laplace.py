@@ -64,24 +64,28 @@ def _families(model, likparms):
 # posterior mean — R/vecchia_prediction.R:17-56 (mean part), :118-142
 # ---------------------------------------------------------------------------
 def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", return_values="mean", device=0):
-    """Posterior mean of the latent field at the observed locations (mu.obs, original order).
-    Variances (SelInv) and prediction locations are not built yet."""
+    """Posterior mean of the latent field at the observed (mu.obs) and prediction (mu.pred) locations, each in the
+    caller's order.  Fully observed 'SGV'/'z' plans: set kernel + posterior pass + mean sweeps on the GPU; plans with
+    prediction locations or 'zy' conditioning: U on the GPU, V and the two triangular solves on the host like the
+    reference's Matrix calls (R/vecchia_prediction.R:62-142).  Variances (SelInv) are not built."""
     va = vecchia_approx
     z, nug = A._removeNAs(z, nuggets)
     n = int(np.sum(va["obs"]))
-    if va["cond_yz"] in ("SGV", "z", "false") and isinstance(covmodel, str) and not np.any(nug == 0):
+    plain = (n == va["locsord"].shape[0]) and va["cond_yz"] in ("SGV", "z", "false")
+    if plain and isinstance(covmodel, str) and not np.any(nug == 0):
         plan = A._plan_for(va, device)
         if not plan.has_posterior:
             plan.build_posterior()
         plan.set_data(z[va["ord_z"] - 1])
         plan.eval(covmodel, covparms, A._device_nuggets(va, nug), GPV_WANT_MEAN)
-        mu_ord = plan.posterior_mean()
-    else:
-        U_obj = A.createU(va, covparms, nug, covmodel, device=device)
-        mu_ord = A.vecchia_mean_host(z, U_obj)
-    mu = np.empty(n)
-    mu[va["ord"] - 1] = mu_ord                                            # orig.order = order(U.obj$ord), :135-136
-    return dict(mu_obs=mu, mu_pred=np.empty(0), var_obs=None, var_pred=None)
+        mu = np.empty(n)
+        mu[va["ord"] - 1] = plan.posterior_mean()                         # orig.order = order(U.obj$ord), :135-136
+        return dict(mu_obs=mu, mu_pred=np.empty(0), var_obs=None, var_pred=None)
+    U_obj = A.createU(va, covparms, nug, covmodel, device=device)
+    if U_obj["zero_nugg"]:
+        raise NotImplementedError("posterior mean with zero nuggets (R/vecchia_prediction.R:129-132) is not built")
+    mu_obs, mu_pred = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)
+    return dict(mu_obs=mu_obs, mu_pred=mu_pred, var_obs=None, var_pred=None)
 
 
 # ---------------------------------------------------------------------------

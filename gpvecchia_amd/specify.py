@@ -75,6 +75,56 @@ def order_maxmin_exact(locs, native=True):
     return order + 1
 
 
+def get_knn(x, k, workers=-1):
+    """FNN::get.knn(x, k)$nn.index (R/vecchia_specify.R:199, R/ordering_functions.R:189): the k nearest OTHER points of
+    every point by ascending distance.  1-based (n, k)."""
+    from scipy.spatial import cKDTree
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = x.shape[0]
+    k = int(min(k, n - 1))
+    _, ind = cKDTree(x).query(x, k=k + 1, workers=workers)
+    ind = ind.reshape(n, -1)
+    own = ind == np.arange(n)[:, None]
+    # drop the point itself (first hit unless an exact duplicate sorts before it; then drop the last column instead)
+    drop = np.where(own.any(axis=1), own.argmax(axis=1), k)
+    keep = np.ones_like(ind, dtype=bool)
+    keep[np.arange(n), drop] = False
+    return ind[keep].reshape(n, k) + 1
+
+
+def order_maxmin_exact_obs_pred(locs, locs_pred):
+    """R/ordering_functions.R:174-218: maxmin ordering of the observed locations, then the prediction locations in their
+    own maxmin order, each moved to the end while one of its nearest neighbours is still ahead of it.
+    Returns (ord, ord_pred), 1-based."""
+    locs = np.ascontiguousarray(locs, dtype=np.float64)
+    locs_pred = np.ascontiguousarray(locs_pred, dtype=np.float64)
+    ord_ = order_maxmin_exact(locs)
+    ord_pred = order_maxmin_exact(locs_pred)
+    n, n_pred = locs.shape[0], locs_pred.shape[0]
+    m = int(min(round(np.sqrt(n)), 200))                                  # :185
+    NN = get_knn(np.vstack([locs, locs_pred]), m)                         # :189
+    iip = np.concatenate([ord_, n + ord_pred, np.zeros(2 * n_pred + 8, dtype=np.int64)]).astype(np.int64)   # 0 = NA
+    poi = np.zeros(n + n_pred + 1, dtype=np.int64)
+    poi[iip[: n + n_pred]] = np.arange(1, n + n_pred + 1)
+    curlen, nmoved, N = n + n_pred, 0, n + n_pred
+    for j in range(n + 1, n + 2 * n_pred + 1):                            # :199
+        idx = iip[j - 1] if j <= iip.size else 0
+        if idx == 0:
+            continue
+        nneigh = int(round(min(m, N / (j - nmoved + 1))))                 # :203
+        nneigh = max(nneigh, 1)                                           # R: NN[i, 1:0] is column 1 (index 0 is dropped)
+        if poi[NN[idx - 1, :nneigh]].min() < j:                           # :205
+            nmoved += 1
+            curlen += 1
+            poi[idx] = curlen
+            if curlen > iip.size:
+                iip = np.concatenate([iip, np.zeros(iip.size, dtype=np.int64)])
+            iip[curlen - 1] = idx
+            iip[j - 1] = 0
+    kept = iip[iip != 0]
+    return ord_, kept[n: n + n_pred] - n                                  # :214
+
+
 # ---------------------------------------------------------------------------
 # ordered nearest neighbours — R/NN_kdtree.R:73-83 semantics
 # ---------------------------------------------------------------------------

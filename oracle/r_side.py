@@ -244,6 +244,55 @@ def findOrderedNN(locs, m):
     return NN
 
 
+def get_knn(x, k):
+    """FNN::get.knn(x, k)$nn.index: the k nearest OTHER points of every point, ascending distance (ties: FNN's kd-tree
+    order is unspecified; lower index here).  Returns 1-based (n, k)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[0]
+    out = np.zeros((n, k), dtype=np.int64)
+    for i in range(n):
+        d = rdist(x, x[i: i + 1])[:, 0]
+        d[i] = np.inf                                                   # the point itself is not its own neighbour
+        out[i] = np.argsort(d, kind="stable")[:k] + 1
+    return out
+
+
+def order_maxmin_exact_obs_pred(locs, locs_pred):
+    """R/ordering_functions.R:174-218, literal (1-based bookkeeping kept)."""
+    locs = np.asarray(locs, dtype=np.float64)
+    locs_pred = np.asarray(locs_pred, dtype=np.float64)
+    ord_ = order_maxmin_exact(locs)                                     # :176
+    ord_pred = order_maxmin_exact(locs_pred)                            # :177
+    locs_all = np.vstack([locs, locs_pred])                             # :182
+    n = locs.shape[0]
+    m = int(min(round(np.sqrt(n)), 200))                                # :185 (R rounds half to even, like Python)
+    n_pred = locs_pred.shape[0]
+    NN = get_knn(locs_all, m)                                           # :189
+    NA = -1
+    iip = np.concatenate([ord_, n + ord_pred, np.full(n_pred, NA)]).astype(np.int64)   # index_in_position, :192
+    poi = np.zeros(n + n_pred + 1, dtype=np.float64)                    # position_of_index (1-based), :193
+    poi[iip[: n + n_pred]] = np.arange(1, n + n_pred + 1)
+    curlen = n + n_pred                                                 # :197
+    nmoved = 0
+    for j in range(n + 1, n + 2 * n_pred + 1):                          # :199
+        nneigh = int(round(min(m, 1 * (n + n_pred) / (j - nmoved + 1))))   # :203
+        idx = iip[j - 1] if j <= len(iip) else NA
+        if idx == NA:                                                   # NN[NA, ] is NA: min(..., na.rm = TRUE) = Inf, no move
+            continue
+        cols = list(range(1, nneigh + 1)) if nneigh >= 1 else [1]       # R: 1:0 == c(1, 0) and index 0 is dropped
+        neighbors = NN[idx - 1, [c - 1 for c in cols]]                  # :204
+        if np.min(poi[neighbors]) < j:                                  # :205
+            nmoved += 1
+            curlen += 1
+            poi[idx] = curlen
+            if curlen > len(iip):                                       # R vectors grow on assignment past the end
+                iip = np.concatenate([iip, np.full(curlen - len(iip), NA)])
+            iip[curlen - 1] = idx
+            iip[j - 1] = NA
+    kept = iip[iip != NA]
+    return ord_, kept[n: n + n_pred] - n                                # :214
+
+
 def whichCondOnLatent(NNarray, firstind_pred=None):
     """R/whichCondOnLatent.R:2-26 — the SGV rule, literal (including R's
     is.element(NA, NA) == TRUE semantics on the first rows)."""
@@ -325,36 +374,79 @@ def U_sparsity(locs, NNarray, obs, Cond):
                 y_ind=latent_map, observed_map=observed_map)
 
 
-def vecchia_specify(locs, m, ordering=None, cond_yz=None, NNarray=None):
-    """R/vecchia_specify.R:29-240 — the no-prediction, conditioning='NN' subset.
+def vecchia_specify(locs, m, ordering=None, cond_yz=None, NNarray=None, locs_pred=None, ordering_pred=None,
+                    pred_cond=None):
+    """R/vecchia_specify.R:29-240 for conditioning='NN' (no MRA), with or without prediction locations.
 
-    ordering in {'none','coord','maxmin'}; cond_yz in {'z','y','SGV'}.
-    NNarray may be supplied (1-based, NaN padded) to bypass the NN search."""
+    ordering in {'none','coord','maxmin'}; cond_yz in {'z','y','SGV','SGVT','zy','RVP','LK'}.
+    NNarray may be supplied (1-based, NaN padded) to bypass the NN search (no-prediction case only)."""
     locs = np.asarray(locs, dtype=np.float64)
     n, dim = locs.shape
+    have_pred = locs_pred is not None
+    if have_pred:
+        locs_pred = np.asarray(locs_pred, dtype=np.float64)
+        la = np.vstack([locs, locs_pred])                               # :47-51
+        if len({tuple(r) for r in la.tolist()}) < la.shape[0]:
+            raise ValueError("Prediction locations contain observed location(s), remove redundancies.")
     if m > n:                                                       # :53-56
         m = n - 1
     if ordering is None:                                            # :83-85
         ordering = "coord" if dim == 1 else "maxmin"
+    if pred_cond is None:                                           # :86
+        pred_cond = "general"
     if cond_yz is None:                                             # :92-96
-        cond_yz = "SGV"
-    if ordering == "coord":                                         # :102
-        ord_ = order_coordinate(locs)
-    elif ordering == "maxmin":                                      # :103-106
-        o = order_maxmin_exact(locs)
-        cut = min(n, 9)
-        ord_ = np.concatenate([o[:1], o[cut:], o[1:cut]])
-    elif ordering == "none":                                        # :109-110
-        ord_ = np.arange(1, n + 1)
-    else:
-        raise ValueError(ordering)
-    locsord = locs[ord_ - 1]
-    obs = np.ones(n, dtype=bool)
+        cond_yz = "SGV" if (not have_pred or dim == 1) else "zy"
+    if not have_pred:                                               # :100-117
+        if ordering == "coord":                                         # :102
+            ord_ = order_coordinate(locs)
+        elif ordering == "maxmin":                                      # :103-106
+            o = order_maxmin_exact(locs)
+            cut = min(n, 9)
+            ord_ = np.concatenate([o[:1], o[cut:], o[1:cut]])
+        elif ordering == "none":                                        # :109-110
+            ord_ = np.arange(1, n + 1)
+        else:
+            raise ValueError(ordering)
+        ord_z = ord_.copy()
+        locsord = locs[ord_ - 1]
+        obs = np.ones(n, dtype=bool)
+        ordering_pred = "general"
+        n_p = 0
+    else:                                                           # :119-149
+        n_p = locs_pred.shape[0]
+        locs_all = np.vstack([locs, locs_pred])
+        observed_obspred = np.concatenate([np.ones(n, bool), np.zeros(n_p, bool)])
+        if ordering_pred is None:                                       # :124-126
+            ordering_pred = "general" if (dim == 1 and ordering == "coord") else "obspred"
+        if ordering_pred == "general":                                  # :127-131
+            ord_ = order_coordinate(locs_all) if ordering == "coord" else order_maxmin_exact(locs_all)
+            ord_obs = ord_[ord_ <= n]
+        else:                                                           # :132-145
+            if ordering == "coord":
+                ord_obs = order_coordinate(locs)
+                ord_pred = order_coordinate(locs_pred)
+            elif ordering == "none":
+                ord_obs = np.arange(1, n + 1)
+                ord_pred = np.arange(1, n_p + 1)
+            else:
+                ord_obs, ord_pred = order_maxmin_exact_obs_pred(locs, locs_pred)
+            ord_ = np.concatenate([ord_obs, ord_pred + n])
+        ord_z = ord_obs
+        locsord = locs_all[ord_ - 1]
+        obs = observed_obspred[ord_ - 1]
     if NNarray is None:
         NNarray = findOrderedNN(locsord, m)                         # :157-159 (semantic twin)
     NNarray = np.asarray(NNarray, dtype=np.float64)
+    if have_pred and pred_cond == "independent":                    # :168-178
+        if ordering_pred == "obspred":
+            for j in range(1, n_p + 1):
+                dists = rdist(locsord[n + j - 1: n + j], locsord[:n])[0]
+                m_nearest = np.sort(np.argsort(dists, kind="stable")[:m] + 1)[::-1]
+                NNarray[n + j - 1] = np.concatenate([[n + j], m_nearest])
     if cond_yz == "SGV":                                            # :182-183
         Cond = whichCondOnLatent(NNarray, firstind_pred=n + 1)
+    elif cond_yz == "SGVT":                                         # :184-185
+        Cond = np.vstack([whichCondOnLatent(NNarray[:n]), np.ones((n_p, m + 1))])
     elif cond_yz == "y":                                            # :186-187
         Cond = np.full(NNarray.shape, np.nan)
         Cond[~np.isnan(NNarray)] = 1.0
@@ -362,10 +454,35 @@ def vecchia_specify(locs, m, ordering=None, cond_yz=None, NNarray=None):
         Cond = np.full(NNarray.shape, np.nan)
         Cond[~np.isnan(NNarray)] = 0.0
         Cond[:, 0] = 1.0
+    elif cond_yz in ("RVP", "LK", "zy"):                            # :191-223 response-latent trick
+        obs = np.concatenate([np.ones(n, bool), np.zeros(locsord.shape[0], bool)])     # :195
+        locsord = np.vstack([locsord[:n], locsord])                     # :196
+        NNs = get_knn(locsord[:n], m - 1).astype(np.float64)            # :199
+        if cond_yz in ("RVP", "zy"):                                    # :200-203
+            prev = NNs < np.arange(1, n + 1)[:, None]
+            NNs[prev] += n
+        NN_z = np.hstack([np.arange(1, n + 1)[:, None].astype(float), np.full((n, m), np.nan)])      # :206
+        NN_y = np.hstack([(np.arange(1, n + 1) + n)[:, None], np.arange(1, n + 1)[:, None], NNs])   # :207
+        if not have_pred:                                               # :208-210
+            NN_yp = np.zeros((0, m + 1))
+            ordering_pred = "obspred"
+        else:
+            if cond_yz == "zy":                                         # :213-214
+                NN_yp = NNarray[n: n + n_p] + n
+            else:                                                       # :215-218
+                NN_yp = NNarray[n: n + n_p].copy()
+                big = NN_yp > n
+                NN_yp[big] += n
+        NNarray = np.vstack([NN_z, NN_y, NN_yp])                        # :220
+        with np.errstate(invalid="ignore"):
+            Cond = (NNarray > n).astype(np.float64)                     # :223 (NA > n is NA)
+        Cond[np.isnan(NNarray)] = np.nan
+        Cond[:, 0] = 1.0
+        cond_yz = "zy"
     else:
         raise ValueError(cond_yz)
     U_prep = U_sparsity(locsord, NNarray, obs, Cond)                # :230
-    return dict(locsord=locsord, obs=obs, ord=ord_, ord_z=ord_.copy(), ord_pred="general",
+    return dict(locsord=locsord, obs=obs, ord=ord_, ord_z=ord_z, ord_pred=ordering_pred,
                 U_prep=U_prep, cond_yz=cond_yz, ic0=False, conditioning="NN")
 
 
@@ -386,7 +503,8 @@ def createU(va, covparms, nuggets, covmodel="matern"):
     if nug.size == 1:                                               # :74
         nug = np.repeat(nug, n)
     nuggets_all = np.concatenate([nug, np.zeros(int(latent.sum()) - n)])   # :75
-    nuggets_all_ord = nuggets_all[ord_ - 1]                         # :77
+    ord_all = np.concatenate([ord_[:n], ord_ + n]) if va["cond_yz"] == "zy" else ord_   # :76
+    nuggets_all_ord = nuggets_all[ord_all - 1]                      # :77
     nuggets_ord = nuggets_all[va["ord_z"] - 1]                      # :78
     revNN = prep["revNNarray"].copy()
     revCond = prep["revCond"].copy()
@@ -408,6 +526,14 @@ def createU(va, covparms, nuggets, covmodel="matern"):
     # :161-162 sparseMatrix(i=colindices, j=rowpointers, x=...) (duplicates would be summed)
     np.add.at(U, (prep["colindices"] - 1, prep["rowpointers"] - 1), vals)
     obs = va["obs"]
+    if va["cond_yz"] == "zy":                                       # :166-171 rows/columns of the dummy y's
+        dummy = 2 * np.arange(1, n + 1) - 1
+        keepd = np.ones(size, dtype=bool)
+        keepd[dummy - 1] = False
+        U = U[np.ix_(keepd, keepd)]
+        latent = latent[keepd]
+        obs = np.delete(obs, np.arange(n, 2 * n))
+        size = int(keepd.sum())
     zero_nugg = {}
     if np.any(nug == 0):                                            # :173-193, literal
         inds_U = np.where(np.isinf(np.diag(U)))[0]                  # :178
@@ -471,15 +597,31 @@ def ichol(M):
     return R_
 
 
+def revMat(M):
+    """R/vecchia_likelihood.R:103."""
+    return M[::-1, ::-1]
+
+
 def U2V(U_obj):
-    """R/vecchia_prediction.R:62-83 (non-zy, non-obspred): V = t(chol(rev(U_y U_y^T))), or t(ichol(.)) when the
-    approximation was specified with ic0 = TRUE (:76-77)."""
-    Uy = U_obj["U"][U_obj["latent"], :]
-    W = Uy @ Uy.T                                                   # :74
-    Wrev = W[::-1, ::-1]                                            # :75
-    if U_obj.get("ic0", False):
-        return ichol(Wrev).T                                        # :77
-    return np.linalg.cholesky(Wrev)                                 # :80 (lower = t(upper chol))
+    """R/vecchia_prediction.R:62-111: V = t(chol(rev(U_y U_y^T))) (or t(ichol(.)) with ic0 = TRUE, :76-77); for 'zy' the
+    latent block of U reversed (:68-70); for obs-pred ordering the prediction columns unchanged and a Cholesky of the
+    observed block only (:85-107)."""
+    U = U_obj["U"]
+    latent = U_obj["latent"]
+    Uy = U[latent, :]
+    chol_rev = (lambda A: ichol(revMat(A)).T) if U_obj.get("ic0", False) else (lambda A: np.linalg.cholesky(revMat(A)))
+    if U_obj["cond_yz"] == "zy":                                        # :68-70
+        return revMat(Uy[:, latent])
+    if U_obj["ord_pred"] != "obspred":                                  # :72-83
+        return chol_rev(Uy @ Uy.T)
+    last_obs = int(np.max(np.where(~latent)[0])) + 1                    # :87 (1-based position)
+    latents_before = int(latent[:last_obs].sum())                       # :88
+    latents_after = int(latent[last_obs:].sum())                        # :89
+    V_pr = revMat(Uy[:, last_obs:])                                     # :92
+    U_oo = Uy[:latents_before, :last_obs]                               # :95
+    V_oor = chol_rev(U_oo @ U_oo.T)                                     # :96-100
+    V_or = np.vstack([np.zeros((latents_after, latents_before)), V_oor])   # :103-104
+    return np.hstack([V_pr, V_or])                                      # :106
 
 
 def vecchia_likelihood_U(z, U_obj):
@@ -560,8 +702,8 @@ def separable_loglik_condz(va, U_entries, z, nuggets):
 # ----------------------------------------------------------------------------
 # posterior mean and Vecchia-Laplace (R/vecchia_prediction.R, R/vecchia_laplace_NR.R), dense restatements
 # ----------------------------------------------------------------------------
-def vecchia_mean(z, U_obj, V):
-    """R/vecchia_prediction.R:118-142 (no zero nuggets, all observed): returns mu.obs in original order."""
+def vecchia_mean(z, U_obj, V, both=False):
+    """R/vecchia_prediction.R:118-142 (no zero nuggets): mu.obs in original order (and mu.pred with both=True)."""
     from scipy.linalg import solve_triangular
     U = U_obj["U"]
     latent = U_obj["latent"]
@@ -572,15 +714,19 @@ def vecchia_mean(z, U_obj, V):
     mu_rev = -solve_triangular(V.T, temp, lower=False)                 # :125
     mu_ord = mu_rev[::-1]                                              # :126
     orig_order = np.argsort(U_obj["ord"], kind="stable")               # :135
-    return mu_ord[orig_order]                                          # :136-138
+    mu = mu_ord[orig_order]                                            # :136
+    obs_orig = np.asarray(U_obj["obs"])[orig_order]                    # :137
+    if both:
+        return mu[obs_orig], mu[~obs_orig]                             # :138-139
+    return mu[obs_orig]
 
 
-def vecchia_prediction_mean(z, va, covparms, nuggets, covmodel="matern"):
+def vecchia_prediction_mean(z, va, covparms, nuggets, covmodel="matern", both=False):
     """R/vecchia_prediction.R:17-56 with return.values='meanmat' (mean only)."""
     z, nuggets = removeNAs(z, nuggets)                                 # :22
     U_obj = createU(va, covparms, nuggets, covmodel)                   # :25
     V = U2V(U_obj)                                                     # :28
-    return vecchia_mean(z, U_obj, V)                                   # :34
+    return vecchia_mean(z, U_obj, V, both)                             # :34
 
 
 def vl_family(model, likparms=None):

@@ -1,0 +1,118 @@
+"""Plans with prediction locations and the response-latent ('zy' / 'RVP' / 'LK') conditioning modes: vecchia_specify
+(R/vecchia_specify.R:119-149,168-223), createU with unobserved rows and dummy-y removal (R/createU.R:73-78,166-171), U2V
+for 'zy' and obs-pred ordering (R/vecchia_prediction.R:62-111), vecchia_mean with mu.pred (:118-142).  The U entries come
+from the HIP path (gpv_U_NZentries with n != Nlocs); everything is compared with the oracle's literal restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("SGV", "obspred", "general"), ("SGV", "obspred", "independent"), ("SGVT", "obspred", "general"),
+         ("y", "obspred", "general"), ("y", "general", "general"), ("zy", "obspred", "general"),
+         ("zy", "obspred", "independent"), ("RVP", "obspred", "general"), ("LK", "obspred", "general")]
+
+
+def _need_gpu():
+    import gpvecchia_amd as G
+    if G.device_count() < 1:
+        pytest.fail("gpu-marked test but libgpvecchia_hip sees no HIP device")
+    return G
+
+
+def _same_specification(va, vb):
+    for k in ("ord", "ord_z", "obs"):
+        assert np.array_equal(np.asarray(va[k]), np.asarray(vb[k])), k
+    assert np.array_equal(va["locsord"], vb["locsord"]) and va["cond_yz"] == vb["cond_yz"] and va["ord_pred"] == vb["ord_pred"]
+    pa, pb = va["U_prep"], vb["U_prep"]
+    assert np.array_equal(pa["revNNarray"], np.nan_to_num(pb["revNNarray"]).astype(np.int32))
+    assert np.array_equal(pa["revCond"], np.nan_to_num(pb["revCond"], nan=-1).astype(np.int8))
+    for k in ("rowpointers", "colindices", "y_ind", "size"):
+        assert np.array_equal(np.asarray(pa[k]), np.asarray(pb[k])), k
+
+
+@pytest.mark.parametrize("cond,ordering_pred,pred_cond", CASES)
+@pytest.mark.parametrize("ordering,d", [("maxmin", 2), ("none", 3)])
+def test_prediction_plans_match_oracle(cond, ordering_pred, pred_cond, ordering, d):
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(len(cond) + 7 * d)
+    n, n_p, m = 260, 90, 12
+    locs, lp = rng.random((n, d)), rng.random((n_p, d))
+    cp = [1.2, 0.25, 1.5]
+    tau = 0.05 + 0.2 * rng.random(n)
+    z = np.linalg.cholesky(R.MaternFun(R.rdist(locs), cp) + np.diag(tau)) @ rng.standard_normal(n)
+    kw = dict(ordering=ordering, cond_yz=cond, locs_pred=lp, ordering_pred=ordering_pred, pred_cond=pred_cond)
+    vb = R.vecchia_specify(locs, m, **kw)
+    va = G.vecchia_specify(locs, m, **kw)
+    _same_specification(va, vb)
+    # createU: n = 260 observations on 350 (or, with the 'zy' trick, 610) rows of locsord
+    refU = R.createU(vb, cp, tau)
+    U = G.createU(va, cp, tau)
+    assert refU["U_entries"]["n_failed"] == 0
+    scale = np.maximum(np.abs(refU["U_entries"]["Lentries"]).max(axis=1), 1e-300)
+    assert (np.abs(U["Lentries"] - refU["U_entries"]["Lentries"]).max(axis=1) / scale).max() < 1e-8
+    np.testing.assert_allclose(U["Zentries"], refU["U_entries"]["Zentries"], rtol=1e-15)
+    assert U["U"].shape == refU["U"].shape and np.array_equal(U["latent"], refU["latent"]) and np.array_equal(U["obs"], refU["obs"])
+    np.testing.assert_allclose(U["U"].toarray(), refU["U"], rtol=0, atol=1e-8 * np.abs(refU["U"]).max())
+    # likelihood and prediction
+    ll_ref = R.vecchia_likelihood(z, vb, cp, tau)
+    with pytest.warns(UserWarning) if va["cond_yz"] == "zy" else _nullcontext():
+        ll = G.vecchia_likelihood(z, va, cp, tau)
+    assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
+    mo_ref, mp_ref = R.vecchia_prediction_mean(z, vb, cp, tau, both=True)
+    pred = G.vecchia_prediction(z, va, cp, tau)
+    assert pred["mu_obs"].shape == (n,) and pred["mu_pred"].shape == (n_p,)
+    np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
+    np.testing.assert_allclose(pred["mu_pred"], mp_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
+    # kriging sanity: the Vecchia prediction is close to the exact conditional mean
+    K = R.MaternFun(R.rdist(np.vstack([locs, lp])), cp)
+    exact = K[n:, :n] @ np.linalg.solve(K[:n, :n] + np.diag(tau), z)
+    assert np.sqrt(np.mean((pred["mu_pred"] - exact) ** 2)) < 0.2 * np.std(exact) + 0.05
+
+
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+@pytest.mark.parametrize("cond", ["zy", "RVP", "LK"])
+def test_response_latent_without_prediction(cond):
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(5)
+    n, m = 300, 9
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    cp, tau = [1.0, 0.2, 0.5], 0.1
+    vb = R.vecchia_specify(locs, m, cond_yz=cond)
+    va = G.vecchia_specify(locs, m, cond_yz=cond)
+    _same_specification(va, vb)
+    refU = R.createU(vb, cp, tau)
+    U = G.createU(va, cp, tau)
+    np.testing.assert_allclose(U["U"].toarray(), refU["U"], rtol=0, atol=1e-8 * np.abs(refU["U"]).max())
+    ll_ref = R.vecchia_likelihood(z, vb, cp, tau)
+    with pytest.warns(UserWarning):
+        ll = G.vecchia_likelihood(z, va, cp, tau)
+    assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
+    mo_ref, mp_ref = R.vecchia_prediction_mean(z, vb, cp, tau, both=True)
+    pred = G.vecchia_prediction(z, va, cp, tau)
+    np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8)
+    assert pred["mu_pred"].size == 0 and mp_ref.size == 0
+
+
+def test_invalid_prediction_specifications():
+    G = _need_gpu()
+    rng = np.random.default_rng(0)
+    locs, lp = rng.random((80, 2)), rng.random((30, 2))
+    with pytest.raises(ValueError):
+        G.vecchia_specify(locs, 5, locs_pred=np.vstack([lp, locs[:1]]))        # R/vecchia_specify.R:47-51
+    with pytest.raises(ValueError):
+        G.vecchia_specify(locs, 5, cond_yz="z", locs_pred=lp)
+    with pytest.raises(ValueError):
+        G.vecchia_specify(locs, 5, cond_yz="SGV", locs_pred=lp, ordering_pred="general")
+    va = G.vecchia_specify(locs[:, :1], 5, locs_pred=lp[:, :1])               # 1-D defaults: coord, SGV, general (:83-96,124-126)
+    assert va["cond_yz"] == "SGV" and va["ord_pred"] == "general"
+    va = G.vecchia_specify(locs, 5, locs_pred=lp)                             # 2-D defaults: maxmin, zy, obspred
+    assert va["cond_yz"] == "zy" and va["ord_pred"] == "obspred" and va["locsord"].shape[0] == 2 * 80 + 30
