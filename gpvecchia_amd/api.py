@@ -653,12 +653,13 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         warnings.warn("cond.yz='zy' will produce a poor likelihood approximation. Use 'SGV' instead.")
     z, nug = _removeNAs(z, nuggets)
     n = int(np.sum(va["obs"]))
-    if va["cond_yz"] in ("z", "false") and isinstance(covmodel, str) and not np.any(nug == 0):
+    plain = n == va["locsord"].shape[0]                  # every row of locsord observed: the fused device paths apply
+    if plain and va["cond_yz"] in ("z", "false") and isinstance(covmodel, str) and not np.any(nug == 0):
         plan = _plan_for(va, device)
         plan.set_data(z[va["ord_z"] - 1])
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_LOGLIK_Z)
         return loglik_z_from_sums(plan.sums(), n)
-    if va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0):     # ic0 changes nothing: no fill
+    if plain and va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0):     # ic0 changes nothing: no fill
         # default mode: U, the numerator AND the posterior pass (U2V) on the GPU; SGV has no fill, so the
         # fixed-pattern factorisation equals the reference's Matrix::chol (R/vecchia_prediction.R:80)
         plan = _plan_for(va, device)

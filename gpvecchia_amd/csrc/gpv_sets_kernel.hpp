@@ -66,7 +66,7 @@ namespace gpv {
 #define GPV_DPP 1
 #endif
 #ifndef GPV_DPP_MINP
-#define GPV_DPP_MINP 22        // below: the denser lane packing of the LDS path wins (measured)
+#define GPV_DPP_MINP 12        // P = 16, 21: -14 %, -5 % against the LDS path; P = 11: +8 % (12 lanes x 5 sets per wave win)
 #endif
 #ifndef GPV_DPP_MAXP
 #define GPV_DPP_MAXP 48        // 3 rows per lane; 4 rows of > 48 columns do not fit the 512 registers

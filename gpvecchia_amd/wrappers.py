@@ -1,13 +1,16 @@
 """Parameter estimation driver — mirror of vecchia_estimate (R/vecchia_wrappers.R:28-106).
 
 The driver is WHY the engine's metric is "likelihood evaluations per second": the plan is specified once
-(:55) and vecchia_likelihood is called once per Nelder-Mead step (:72-78, up to maxit = 300) with continuously
-varying smoothness, i.e. through the general-nu Bessel branch on the device.
+(:55) and vecchia_likelihood is called once per Nelder-Mead step (:72-78, up to maxit = 300 evaluations) with
+continuously varying smoothness, i.e. through the general-nu Bessel branch on the device.
 
-Deviation from the reference, stated plainly: R's stats::optim runs its own Nelder-Mead variant (nmmin); it is
-R-core code that is not part of the GPvecchia tree and R is not installed here, so scipy's Nelder-Mead is used
-with the same objective, the same log-parametrisation, the same parscale idea, maxiter = 300 and a relative
-function tolerance.  Optimiser paths therefore differ from R's; the optimum they approach is the same function's.
+stats::optim(method = "Nelder-Mead") is R-core code outside the GPvecchia tree: its simplex search is Nash's
+(Compact Numerical Methods, 2nd ed., 1990, algorithm 19) with alpha = 1, beta = 0.5, gamma = 2, started from the
+axis-parallel simplex of step 0.1 max|x_i|, stopped when f_high <= f_low + reltol (|f_initial| + reltol) or after
+`maxit` function evaluations.  `_nelder_mead_nash` below follows that published algorithm and those control values
+(reltol, maxit, parscale as used at :83-93).  Pinned by the known answer printed in R's own documentation of optim
+(example `optim(c(-1.2, 1), fr)` on the Rosenbrock function: par 1.000260 1.000506, value 8.825241e-08, 195 function
+evaluations), reproduced digit for digit in tests/test_cabi_and_host.py.
 """
 from __future__ import annotations
 
@@ -15,9 +18,92 @@ import numpy as np
 
 from . import api as A
 
+_BIG = 1.0e35          # value substituted for a non-finite objective (as optim does)
+
+
+def _nelder_mead_nash(fn, x0, reltol, maxit, abstol=-np.inf, alpha=1.0, beta=0.5, gamma=2.0):
+    """Nelder-Mead polytope search after Nash (1990).  Returns (x, f, n_evals, code): code 0 converged, 1 evaluation
+    limit reached, 10 degenerate simplex (the codes optim reports)."""
+    x0 = np.asarray(x0, dtype=np.float64)
+    n = x0.size
+    f0 = fn(x0)
+    if not np.isfinite(f0):
+        raise RuntimeError("function cannot be evaluated at initial parameters")
+    count = 1
+    convtol = reltol * (abs(f0) + reltol)
+    V = np.tile(x0, (n + 1, 1))                      # vertices
+    F = np.full(n + 1, np.nan)
+    F[0] = f0
+    step = max(0.1 * np.max(np.abs(x0)), 0.0) or 0.1
+    size = 0.0
+    for j in range(1, n + 1):
+        t = step
+        while V[j, j - 1] == x0[j - 1]:
+            V[j, j - 1] = x0[j - 1] + t
+            t *= 10
+        size += t
+    oldsize = size
+    lo = 0
+    recompute = True
+    code = 0
+    while True:
+        if recompute:
+            for j in range(n + 1):
+                if j != lo:
+                    f = fn(V[j])
+                    F[j] = f if np.isfinite(f) else _BIG
+                    count += 1
+            recompute = False
+        lo = int(np.argmin(F))                       # first minimum / maximum, like the running comparisons of the original
+        hi = int(np.argmax(F))
+        fl, fh = F[lo], F[hi]
+        if fh <= fl + convtol or fl <= abstol:
+            break
+        cen = (V.sum(axis=0) - V[hi]) / n
+        xr = (1.0 + alpha) * cen - alpha * V[hi]
+        fr = fn(xr)
+        fr = fr if np.isfinite(fr) else _BIG
+        count += 1
+        if fr < fl:                                  # try an extension
+            xe = gamma * xr + (1.0 - gamma) * cen
+            fe = fn(xe)
+            fe = fe if np.isfinite(fe) else _BIG
+            count += 1
+            if fe < fr:
+                V[hi], F[hi] = xe, fe
+            else:
+                V[hi], F[hi] = xr, fr
+        else:
+            if fr < fh:                              # keep the reflection, then reduce on the low side
+                V[hi], F[hi] = xr, fr
+            xc = (1.0 - beta) * V[hi] + beta * cen
+            fc = fn(xc)
+            fc = fc if np.isfinite(fc) else _BIG
+            count += 1
+            if fc < F[hi]:
+                V[hi], F[hi] = xc, fc
+            elif fr >= fh:                           # shrink towards the best vertex
+                recompute = True
+                size = 0.0
+                for j in range(n + 1):
+                    if j != lo:
+                        V[j] = beta * (V[j] - V[lo]) + V[lo]
+                        size += np.abs(V[j] - V[lo]).sum()
+                if size < oldsize:
+                    oldsize = size
+                else:
+                    code = 10
+                    break
+        if count > maxit:
+            break
+    lo = int(np.argmin(F))
+    if count > maxit:
+        code = 1
+    return V[lo].copy(), float(F[lo]), count, code
+
 
 def vecchia_estimate(data, locs, X="missing", m=20, covmodel="matern", theta_ini=None, output_level=1,
-                     reltol=np.sqrt(np.finfo(float).eps), seed=0, **specify_args):
+                     reltol=np.sqrt(np.finfo(float).eps), seed=0, maxit=300, **specify_args):
     data = np.asarray(data, dtype=np.float64)
     locs = np.asarray(locs, dtype=np.float64)
     if isinstance(X, str) and X == "missing":                        # :32-37 constant trend
@@ -53,20 +139,19 @@ def vecchia_estimate(data, locs, X="missing", m=20, covmodel="matern", theta_ini
         th = np.exp(lg)
         return -A.vecchia_likelihood(z, va, th[:-1], th[-1], covmodel=covmodel)
 
-    from scipy.optimize import minimize
-    parscale = np.ones(n_par)                                        # :83-85
-    non1 = theta_ini != 1
+    parscale = np.ones(n_par)                                        # :83-85 (entries with theta.ini == 1 stay 1; the
+    non1 = theta_ini != 1                                            #  reference's rep(1, length(n.par)) leaves them NA)
     parscale[non1] = np.log(theta_ini[non1])
-    x0 = np.log(theta_ini) / parscale
-    res = minimize(lambda x: negloglik(x * parscale), x0, method="Nelder-Mead",
-                   options=dict(maxiter=300, xatol=1e-10, fatol=0.0, adaptive=False,
-                                initial_simplex=None), tol=None)
-    # R's reltol test (f_high - f_low <= reltol * (|f_low| + reltol)) is approximated by a restart-free single run;
-    # scipy stops on maxiter or xatol.
+    x0 = np.log(theta_ini) / parscale                                # optim works on par / parscale
+    xbest, fbest, _, conv = _nelder_mead_nash(lambda x: negloglik(x * parscale), x0, reltol=reltol, maxit=maxit)   # :87-93
+
+    class _Res:
+        x, fun = xbest, fbest
+    res = _Res()
     theta_hat = np.exp(res.x * parscale)
     if output_level > 0:                                             # :98-101
         print("estimated trend coefficients:\n", beta_hat)
         print("estimated covariance parameters:\n",
               dict(zip(("variance", "range", "smoothness", "nugget"), theta_hat)))
     return dict(z=z, beta_hat=beta_hat, theta_hat=theta_hat, trend=trend, locs=locs, covmodel=covmodel,
-                n_evals=evals[0], neg_loglik=float(res.fun))
+                n_evals=evals[0], neg_loglik=float(res.fun), convergence=conv)

@@ -248,3 +248,18 @@ def test_ic0_native_matches_reference_restatement():
     ptrs = np.array([0, 1, 3], dtype=np.int32); inds = np.array([0, 0, 1], dtype=np.int32)
     vals = np.array([1.0, 2.0, 1.0]); nbad = C.c_int64(0)
     assert L.lib().gpv_ic0(2, L.iptr(ptrs), L.iptr(inds), L.dptr(vals), C.byref(nbad)) == 0 and nbad.value == 1
+
+
+def test_nelder_mead_reproduces_the_known_answer_of_R_optim():
+    # stats::optim(method = "Nelder-Mead") is what vecchia_estimate drives (R/vecchia_wrappers.R:87-93).  R's documentation
+    # of optim prints, for `fr <- function(x) 100 * (x[2] - x[1]^2)^2 + (1 - x[1])^2; optim(c(-1.2, 1), fr)`:
+    #   $par 1.000260 1.000506   $value 8.825241e-08   $counts function 195   $convergence 0
+    from gpvecchia_amd.wrappers import _nelder_mead_nash
+    fr = lambda x: 100 * (x[1] - x[0] ** 2) ** 2 + (1 - x[0]) ** 2
+    x, f, count, code = _nelder_mead_nash(fr, [-1.2, 1.0], reltol=np.sqrt(np.finfo(float).eps), maxit=500)
+    assert count == 195 and code == 0
+    assert abs(x[0] - 1.000260) < 5e-7 and abs(x[1] - 1.000506) < 5e-7
+    assert abs(f - 8.825241e-08) < 5e-14
+    # evaluation limit -> convergence code 1 (optim's maxit counts function evaluations for this method)
+    _, _, c2, code2 = _nelder_mead_nash(fr, [-1.2, 1.0], reltol=1e-12, maxit=50)
+    assert code2 == 1 and 50 < c2 <= 53

@@ -1,11 +1,12 @@
 """Developer tool: turn the scratch output of tools/profile_round.sh (gpurun_out/<tag>/) into the tracked artefacts under
 profiles/: <name>_bench.json, <name>_kernel_stats.csv, <name>_pmc_pass<i>.csv (set-kernel rows only), <name>_pmc_summary.json
-and r01_pmc_traffic.json (the per-launch HBM traffic bench.py quotes).
+and r02_pmc_traffic.json (the per-launch HBM traffic bench.py quotes while the kernel source hash matches).
 
-    python tools/collect_profiles.py gpurun_out/r01f r01_final
+    python tools/collect_profiles.py gpurun_out/r02 r02
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -49,13 +50,16 @@ if "GRBM_GUI_ACTIVE" in tot:
     }
 json.dump(tot, open(os.path.join(P, name + "_pmc_summary.json"), "w"), indent=1)
 if "FETCH_SIZE" in tot:
+    ksrc = open(os.path.join(ROOT, "gpvecchia_amd", "csrc", "gpv_sets_kernel.hpp"), "rb").read()
     json.dump({
         "hbm_bytes_per_launch": (tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0)) * 1024,
         "fetch_size_kb": tot["FETCH_SIZE"], "write_size_kb": tot.get("WRITE_SIZE", 0),
-        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), last launch of the set kernel in bench.py at "
-                "n=1e6 m=30 mode L; raw counter x 1024 B, NOT doubled: the gfx950 x2 correction is calibrated for wide "
-                "coalesced streams only, this kernel mixes a 155 MB coalesced index/flag stream with 32-byte gathers served "
-                "by L2/Infinity Cache",
-    }, open(os.path.join(P, "r01_pmc_traffic.json"), "w"), indent=1)
+        "kernel_source_sha256": hashlib.sha256(ksrc).hexdigest(),
+        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/profile_round.sh), last launch of the set "
+                "kernel in bench.py at n=1e6 m=30 mode L; raw counter x 1024 B, NOT doubled: the gfx950 x2 correction is "
+                "calibrated for wide coalesced streams only, this kernel mixes a 155 MB coalesced index/flag stream with "
+                "32-byte gathers served by L2/Infinity Cache (2x the figure is the upper bound).  bench.py quotes the figure "
+                "only while gpv_sets_kernel.hpp hashes to kernel_source_sha256.",
+    }, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(tot.get("_derived", {}), indent=1))
 print(line[:400])
