@@ -339,7 +339,8 @@ def vecchia_specify(locs, m=-1, ordering=None, cond_yz=None, locs_pred=None, ord
     if NNarray is None:                                                      # :157-159
         # both searches implement the same exact definition and return identical arrays (tests); "gpu" is the
         # library's brute-force kernel, "host" the cKDTree search
-        use_gpu = nn_backend == "gpu" or (nn_backend == "auto" and L.device_count() > 0 and nall >= 2000)
+        use_gpu = (nn_backend == "gpu" or (nn_backend == "auto" and L.device_count() > 0 and nall >= 2000)) and \
+            spatial_dim <= 8 and m <= 255                                    # limits of the brute-force kernel
         NNarray = S.find_ordered_nn_gpu(locsord, m) if use_gpu else S.find_ordered_nn(locsord, m)
     NNarray = np.asarray(NNarray).astype(np.int32)
     if have_pred and pred_cond == "independent":                             # :168-178
@@ -659,7 +660,8 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         plan.set_data(z[va["ord_z"] - 1])
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_LOGLIK_Z)
         return loglik_z_from_sums(plan.sums(), n)
-    if plain and va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0):     # ic0 changes nothing: no fill
+    if plain and va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0) and \
+            va["U_prep"]["revNNarray"].shape[1] <= 64:                      # ic0 changes nothing: no fill
         # default mode: U, the numerator AND the posterior pass (U2V) on the GPU; SGV has no fill, so the
         # fixed-pattern factorisation equals the reference's Matrix::chol (R/vecchia_prediction.R:80)
         plan = _plan_for(va, device)

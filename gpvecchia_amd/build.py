@@ -75,9 +75,11 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
             work.append((inst, os.path.join(BUILD, f"sets_p{P}.o"), [f"-DGPV_INST_P={P}"] + extra_flags, kern, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), list(extra_flags),
                  kern + H("gpv_plist.h"), force))
-    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub] + H("gpv_laplace.h"), force))
+    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub] + H("gpv_laplace.h", "gpv_generic.h"), force))
     work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), internal, force))
     work.append((os.path.join(CSRC, "gpv_laplace.hip"), os.path.join(BUILD, "laplace.o"), [], H("gpv_laplace.h"), force))
+    work.append((os.path.join(CSRC, "gpv_sets_generic.hip"), os.path.join(BUILD, "generic.o"), list(extra_flags),
+                 kern + H("gpv_generic.h"), force))
     work.append((os.path.join(CSRC, "gpv_order.cpp"), os.path.join(BUILD, "order.o"), ["-x", "c++"], [pub], force))
     work.append((os.path.join(CSRC, "gpv_nn.hip"), os.path.join(BUILD, "nn.o"), ["-ffp-contract=off"], internal + [pub], force))
     jobs = jobs or min(8, os.cpu_count() or 1)

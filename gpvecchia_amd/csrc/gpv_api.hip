@@ -5,6 +5,7 @@
 #include "../../include/gpvecchia.h"
 #include "gpv_internal.h"
 #include "gpv_laplace.h"
+#include "gpv_generic.h"
 
 #include <chrono>
 #include <climits>
@@ -252,6 +253,7 @@ struct gpv_plan {
     double nug_scalar = 0.0;
     bool nug_is_scalar = true;
     uint8_t *d_cond = nullptr;
+    bool generic = false;          // row length > 64 or dimension > 8: workgroup-per-set kernel (gpv_sets_generic.hip)
     // Vecchia-Laplace state (gpv_plan_vl_begin): data z, prior mean, two latent-mean buffers (current / next), flags + max
     double *d_vl_z = nullptr, *d_vl_pm = nullptr, *d_vl_y[2] = {nullptr, nullptr}, *d_vl_out = nullptr;
     int *d_vl_flags = nullptr;
@@ -271,7 +273,7 @@ const char *gpv_status_string(int status)
         case GPV_ERR_BAD_ARG: return "bad argument";
         case GPV_ERR_COVTYPE: return "covariance is not implemented (covType must be \"matern\" or \"esqe\")";
         case GPV_ERR_UNSUPPORTED_NU: return "Matern smoothness must be finite, > 0 and <= 60";
-        case GPV_ERR_UNSUPPORTED_M: return "m+1 exceeds the widest compiled conditioning-set kernel";
+        case GPV_ERR_UNSUPPORTED_M: return "m+1 exceeds 192 (or 64 for the device posterior pass)";
         case GPV_ERR_HIP: return "HIP runtime error";
         case GPV_ERR_STATE: return "call order error (no evaluation yet / no data set)";
         case GPV_ERR_INDEX: return "neighbour index out of range";
@@ -293,7 +295,7 @@ int gpv_device_count(int *count)
     return c > 0 ? GPV_OK : GPV_ERR_NO_DEVICE;
 }
 
-int gpv_max_p(void) { return max_P(); }
+int gpv_max_p(void) { return generic_max_P(); }
 
 int gpv_plan_destroy(gpv_plan *pl)
 {
@@ -337,14 +339,19 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     PhaseTimer tm;
     if (!out) return GPV_ERR_BAD_ARG;
     *out = nullptr;
-    if (Nlocs <= 0 || Nlocs >= ((int64_t)1 << 31) || dim < 1 || dim > kMaxDimGeneric || ncolNN < 1 || !revNN)
+    if (Nlocs <= 0 || Nlocs >= ((int64_t)1 << 31) || dim < 1 || dim > 4096 || ncolNN < 1 || !revNN)
         return GPV_ERR_BAD_ARG;
     if (row_begin < 0 || row_end > Nlocs || row_begin > row_end) return GPV_ERR_BAD_ARG;
     int ndev = 0;
     if (gpv_device_count(&ndev) != GPV_OK) return GPV_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev) return GPV_ERR_NO_DEVICE;
-    const int P = pick_P(ncolNN);
-    if (P == 0) return GPV_ERR_UNSUPPORTED_M;
+    int P = pick_P(ncolNN);
+    bool generic = false;
+    if (P == 0 || dim > kMaxDimGeneric) {          // shapes without an unrolled instantiation: the slow generic kernel
+        if (ncolNN > generic_max_P()) return GPV_ERR_UNSUPPORTED_M;
+        P = ncolNN;
+        generic = true;
+    }
     if (hipSetDevice(device) != hipSuccess) return GPV_ERR_NO_DEVICE;
 
     gpv_plan *pl = new gpv_plan();
@@ -356,6 +363,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     pl->dim = dim;
     pl->p = ncolNN;
     pl->P = P;
+    pl->generic = generic;
     pl->locs_ld = (dim <= 3) ? 4 : dim;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
@@ -616,7 +624,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         std::memset(&a.bt, 0, sizeof(a.bt));
     }
     GPV_HIP(hipEventRecord(pl->ev0, st));
-    GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
+    if (pl->generic) GPV_HIP(launch_sets_generic(pl->P, a, pl->cus, &pl->grid, st));
+    else GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
     if (flags & GPV_WANT_DENOM) {
@@ -698,6 +707,7 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     // lists, row lists and a level schedule; parameter independent, built once.
     if (!pl || !revNN || !revCond) return GPV_ERR_BAD_ARG;
     if (pl->row_begin != 0 || pl->row_end != pl->Nlocs) return GPV_ERR_BAD_ARG;   // not shardable
+    if (pl->p > 64) return GPV_ERR_UNSUPPORTED_M;      // the level kernels own one lane per row of a column (<= 64)
     if (pl->Nlocs >= (int64_t)1 << 31) return GPV_ERR_BAD_ARG;
     const int64_t n = pl->Nlocs;
     const int p = pl->p;

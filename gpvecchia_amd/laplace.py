@@ -71,7 +71,8 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
     va = vecchia_approx
     z, nug = A._removeNAs(z, nuggets)
     n = int(np.sum(va["obs"]))
-    plain = (n == va["locsord"].shape[0]) and va["cond_yz"] in ("SGV", "z", "false")
+    plain = (n == va["locsord"].shape[0]) and va["cond_yz"] in ("SGV", "z", "false") and \
+        va["U_prep"]["revNNarray"].shape[1] <= 64                           # the device posterior pass handles m + 1 <= 64
     if plain and isinstance(covmodel, str) and not np.any(nug == 0):
         plan = A._plan_for(va, device)
         if not plan.has_posterior:
@@ -155,7 +156,8 @@ def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covpa
     y_o = prior_mean.copy() if y_init is None or np.any(np.isnan(y_init)) else np.asarray(y_init, float).copy()   # :81-82
     va = vecchia_approx
     if (on_device is not False and likelihood_model in _DEVICE_MODELS and obs_inds.size == len(z) and isinstance(covmodel, str)
-            and va["cond_yz"] in ("SGV", "z") and int(np.sum(va["obs"])) == len(z)):
+            and va["cond_yz"] in ("SGV", "z") and int(np.sum(va["obs"])) == len(z)
+            and va["U_prep"]["revNNarray"].shape[1] <= 64):
         return _posterior_VL_device(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, y_o, prior_mean,
                                     fam, verbose, device)
     if on_device is True:

@@ -36,7 +36,8 @@ enum {
     GPV_ERR_BAD_ARG = 2,        /* null pointer, negative size, bad shard range      */
     GPV_ERR_COVTYPE = 3,        /* covType not "matern"/"esqe" (src/U_NZentries.cpp:27-29) */
     GPV_ERR_UNSUPPORTED_NU = 4, /* Matern smoothness not in (0, 60] or not finite                */
-    GPV_ERR_UNSUPPORTED_M = 5,  /* m+1 larger than the widest compiled kernel (64)   */
+    GPV_ERR_UNSUPPORTED_M = 5,  /* m+1 > 192 (m+1 <= 64: unrolled register kernels; up to 192 and any dimension: a slow
+                                   workgroup-per-set kernel); m+1 > 64 for gpv_plan_build_posterior */
     GPV_ERR_HIP = 6,            /* HIP runtime failure (alloc, copy, launch)         */
     GPV_ERR_STATE = 7,          /* call order: result requested before an eval, no data set */
     GPV_ERR_INDEX = 8           /* neighbour index outside [0, Nlocs]                */
@@ -72,7 +73,7 @@ typedef struct gpv_plan gpv_plan;
 const char *gpv_status_string(int status);
 int gpv_version(void);                 /* 100*major + minor */
 int gpv_device_count(int *count);      /* number of visible HIP devices */
-int gpv_max_p(void);                   /* widest supported row length m+1 */
+int gpv_max_p(void);                   /* widest supported row length m+1 (192) */
 
 /* -------------------------------------------------------------------------
  * Literal drop-ins for the reference's native entry points.  Signature shape:

@@ -38,7 +38,7 @@ def test_status_strings_and_pure_host_entry_points():
     from gpvecchia_amd import _lib
     L = _lib.lib()
     assert L.gpv_version() >= 100
-    assert L.gpv_max_p() == 64
+    assert L.gpv_max_p() == 192            # <= 64: unrolled register kernels; up to 192: the generic workgroup-per-set kernel
     for code in range(0, 9):
         assert len(L.gpv_status_string(code)) > 0
     # gpv_loglik_z_from_sums / gpv_numerator_from_sums are host arithmetic: testable without a GPU

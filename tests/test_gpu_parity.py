@@ -320,6 +320,90 @@ def test_failed_rows_and_errors():
     np.testing.assert_allclose(out["Lentries"][3], ref["Lentries"][3], rtol=1e-9, atol=1e-16)
 
 
+@pytest.mark.parametrize("m,d,cond", [(64, 2, "z"), (64, 2, "SGV"), (100, 2, "z"), (100, 3, "y"), (150, 2, "SGV"),
+                                      (191, 2, "z"), (15, 10, "z"), (15, 10, "SGV"), (30, 20, "y"), (70, 12, "z")])
+def test_generic_kernel_long_rows_and_high_dimensions(m, d, cond):
+    # m + 1 > 64 or more than 8 coordinates: the reference takes any m and any dimension (src/U_NZentries.cpp:31,
+    # src/dist.cpp:10-16); served by the workgroup-per-set kernel (gpv_sets_generic.hip)
+    G = _need_gpu()
+    from oracle import r_side as R
+    n = max(260, m + 60)
+    rng = np.random.default_rng(1000 + m + d)
+    locs = rng.random((n, d)); z = rng.standard_normal(n)
+    NN = R.findOrderedNN(locs, m)                                     # vecchia_specify without the O(n m^2) SGV loop of the oracle
+    va = R.vecchia_specify(locs, m, ordering="none", cond_yz=cond, NNarray=NN)
+    cp = [1.3, 0.25 * np.sqrt(d / 2), 0.5 if m > 64 else 1.5]        # the exponential kernel keeps 100+-row blocks well conditioned
+    tau = 0.1 + 0.1 * rng.random(n)
+    ref = R.createU(va, cp, tau)["U_entries"]
+    prep = va["U_prep"]
+    out = G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], tau, tau, "matern", cp)
+    assert out["n_failed"] == ref["n_failed"] == 0
+    _assert_rows_close(out["Lentries"], ref["Lentries"], va, cp, tau)
+    np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
+    np.testing.assert_allclose(out["Zentries"], ref["Zentries"], rtol=1e-15)
+    pva = _to_product_va(va)
+    ll_ref = R.vecchia_likelihood(z, va, cp, tau)
+    assert abs(G.vecchia_likelihood(z, pva, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)
+    if cond == "z":                                                  # fused sums of the generic kernel
+        plan = pva[("_plan", 0)]
+        s = plan.sums()
+        assert s[6] == 0 and s[7] == n
+        _, s_ref = R.separable_loglik_condz(va, ref, z, tau)
+        np.testing.assert_allclose(s[2] + s[3], s_ref[2] - 2 * s_ref[0] + s_ref[1] + s_ref[3] + s_ref[4] - s_ref[5], rtol=1e-9)
+
+
+def test_generic_kernel_edges():
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(4)
+    n, p, d = 300, 80, 2
+    locs = rng.random((n, d))
+    revNN = np.zeros((n, p)); revCond = np.full((n, p), np.nan)
+    for k in range(n):                                               # ragged rows with holes anywhere (src/U_NZentries.cpp:44-47)
+        cand = rng.permutation(k)[: min(k, p - 1)] + 1
+        keep = cand[rng.random(len(cand)) < 0.8]
+        row = np.zeros(p)
+        pos = np.sort(rng.choice(p - 1, size=len(keep), replace=False)) if len(keep) else np.array([], int)
+        row[pos] = keep
+        row[p - 1] = k + 1
+        revNN[k] = row
+        n0 = int((row != 0).sum())
+        c = (rng.random(n0) < 0.5).astype(float); c[-1] = 1
+        revCond[k, p - n0:] = c
+    cp, tau = [1.0, 0.3, 0.5], 0.1 + rng.random(n)
+    ref = R.U_NZentries(1, n, locs, revNN, revCond, tau, tau, "matern", cp)
+    out = G.U_NZentries(1, n, locs, revNN, revCond, tau, tau, "matern", cp)
+    assert out["n_failed"] == ref["n_failed"] == 0
+    assert _row_err(out["Lentries"], ref["Lentries"]) < 1e-8
+    np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
+    # duplicate locations conditioned on as latent: singular block => zero row, counted (:64-66)
+    l2 = locs.copy(); l2[150] = l2[149]
+    rc = np.where(np.isnan(revCond), np.nan, 1.0)
+    rn = revNN.copy(); rn[150] = 0; rn[150, -2:] = [150, 151]; rc[150] = np.nan; rc[150, -2:] = 1
+    ref = R.U_NZentries(1, n, l2, rn, rc, tau, tau, "matern", cp)
+    out = G.U_NZentries(1, n, l2, rn, rc, tau, tau, "matern", cp)
+    assert out["n_failed"] == ref["n_failed"] >= 1 and np.all(out["Lentries"][150] == 0)
+    np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
+    # dense-covariance variant with long rows (src/U_NZentries.cpp:126-197)
+    K = R.MaternFun(R.rdist(locs), cp) + 0.01 * np.eye(n)
+    refm = R.U_NZentries_mat(1, n, locs, revNN, revCond, None, np.full(n, .2), K, None)
+    outm = G.U_NZentries_mat(1, n, locs, revNN, revCond, None, np.full(n, .2), K, None)
+    assert _row_err(outm["Lentries"], refm["Lentries"]) < 1e-8
+    # beyond the LDS-resident limit
+    big = np.zeros((n, 200)); big[:, -1] = np.arange(1, n + 1)
+    with pytest.raises(G.GpvError) as e:
+        G.U_NZentries(1, n, locs, big, np.ones((n, 200)), tau, tau, "matern", cp)
+    assert e.value.status == 5
+    # the device posterior pass stops at m + 1 = 64: longer rows take the host factorisation, same likelihood
+    locs3, z3, va3 = _case(320, 70, 2, 9, "SGV")
+    pva3 = _to_product_va(va3)
+    ll_ref = R.vecchia_likelihood(z3, va3, [1.0, 0.3, 0.5], 0.2)
+    assert abs(G.vecchia_likelihood(z3, pva3, [1.0, 0.3, 0.5], 0.2) - ll_ref) <= LL_RTOL * abs(ll_ref)
+    with pytest.raises(G.GpvError) as e:
+        pva3[("_plan", 0)].build_posterior()
+    assert e.value.status == 5
+
+
 def test_failed_block_gives_minus_inf_loglik():
     # a block that is not positive definite leaves a zero row in U (src/U_NZentries.cpp:64-66): diag(U) = 0,
     # logdet.num = +Inf and the log-likelihood is -Inf (R/vecchia_likelihood.R:76,95-96), not NaN
