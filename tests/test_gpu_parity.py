@@ -332,7 +332,7 @@ def test_generic_kernel_long_rows_and_high_dimensions(m, d, cond):
     locs = rng.random((n, d)); z = rng.standard_normal(n)
     NN = R.findOrderedNN(locs, m)                                     # vecchia_specify without the O(n m^2) SGV loop of the oracle
     va = R.vecchia_specify(locs, m, ordering="none", cond_yz=cond, NNarray=NN)
-    cp = [1.3, 0.25 * np.sqrt(d / 2), 0.5 if m > 64 else 1.5]        # the exponential kernel keeps 100+-row blocks well conditioned
+    cp = [1.3, 0.25 * np.sqrt(d / 2), 0.5 if m >= 64 else 1.5]       # the exponential kernel keeps 65+-row blocks well conditioned
     tau = 0.1 + 0.1 * rng.random(n)
     ref = R.createU(va, cp, tau)["U_entries"]
     prep = va["U_prep"]
@@ -378,7 +378,7 @@ def test_generic_kernel_edges():
     np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
     # duplicate locations conditioned on as latent: singular block => zero row, counted (:64-66)
     l2 = locs.copy(); l2[150] = l2[149]
-    rc = np.where(np.isnan(revCond), np.nan, 1.0)
+    rc = revCond.copy()
     rn = revNN.copy(); rn[150] = 0; rn[150, -2:] = [150, 151]; rc[150] = np.nan; rc[150, -2:] = 1
     ref = R.U_NZentries(1, n, l2, rn, rc, tau, tau, "matern", cp)
     out = G.U_NZentries(1, n, l2, rn, rc, tau, tau, "matern", cp)
