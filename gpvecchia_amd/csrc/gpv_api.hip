@@ -245,8 +245,9 @@ struct gpv_plan {
     double *d_nug_post = nullptr;                    // [Nlocs] nuggets in ordering: fixed kernel argument for the graph
     // general-nu Matern: range of pair distances of the plan (parameter independent) and the per-evaluation table
     double dist_min = 0.0, dist_max = 0.0;
-    double *d_mt = nullptr;
-    std::vector<double> h_mt;
+    double *h_mt2[2] = {nullptr, nullptr}, *d_mt2[2] = {nullptr, nullptr};   // pinned staging / device copies, used alternately
+    hipEvent_t mt_ev[2] = {nullptr, nullptr};
+    int mt_slot = 0, mt_pending = -1;
     int32_t *d_order2 = nullptr;
     double *d_u = nullptr, *d_mu = nullptr;
     bool have_mean = false;
@@ -306,12 +307,16 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt,
+                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    for (int t = 0; t < 2; ++t) {
+        if (pl->h_mt2[t]) (void)hipHostFree(pl->h_mt2[t]);
+        if (pl->mt_ev[t]) (void)hipEventDestroy(pl->mt_ev[t]);
+    }
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
@@ -609,16 +614,26 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
         if (!no_tab && pl->dist_min > 0.0 && pl->dist_max >= pl->dist_min) {
             constexpr int kMaxSeg = 320;                                   // 80 octaves
-            if (!pl->d_mt) GPV_HIP(hipMalloc((void **)&pl->d_mt, sizeof(double) * kMaxSeg * MaternTab::ROW));
-            pl->h_mt.resize((size_t)kMaxSeg * MaternTab::ROW);
-            GPV_HIP(hipStreamSynchronize(st));                             // the previous upload has left h_mt
-            matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, pl->h_mt.data(), &a.mt_base,
+            // the table travels in kernel-argument style: two pinned host staging buffers and two device copies used
+            // alternately, guarded by an event each, so that building the table for this evaluation never waits for the
+            // stream (the previous evaluation may still be reading the other copy)
+            const size_t tabb = sizeof(double) * kMaxSeg * MaternTab::ROW;
+            const int sl = pl->mt_slot ^= 1;
+            if (!pl->h_mt2[sl]) {
+                GPV_HIP(hipHostMalloc((void **)&pl->h_mt2[sl], tabb, hipHostMallocDefault));
+                GPV_HIP(hipMalloc((void **)&pl->d_mt2[sl], tabb));
+                GPV_HIP(hipEventCreateWithFlags(&pl->mt_ev[sl], hipEventDisableTiming));
+            } else {
+                GPV_HIP(hipEventSynchronize(pl->mt_ev[sl]));              // two evaluations ago: long done in steady state
+            }
+            matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, pl->h_mt2[sl], &a.mt_base,
                              &a.mt_nseg, kMaxSeg);
             if (a.mt_nseg > 0) {
-                GPV_HIP(hipMemcpyAsync(pl->d_mt, pl->h_mt.data(), sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
+                GPV_HIP(hipMemcpyAsync(pl->d_mt2[sl], pl->h_mt2[sl], sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
                                        hipMemcpyHostToDevice, st));
-                a.mt = pl->d_mt;
+                a.mt = pl->d_mt2[sl];
             }
+            pl->mt_pending = sl;
         }
     } else {
         std::memset(&a.bt, 0, sizeof(a.bt));
@@ -627,6 +642,10 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     if (pl->generic) GPV_HIP(launch_sets_generic(pl->P, a, pl->cus, &pl->grid, st));
     else GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
     GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
+    if (pl->mt_pending >= 0) {                     // the kernel that reads this evaluation's Matern table has been enqueued
+        GPV_HIP(hipEventRecord(pl->mt_ev[pl->mt_pending], st));
+        pl->mt_pending = -1;
+    }
     GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
     if (flags & GPV_WANT_DENOM) {
         // nuggets as a vector at a fixed address (scalar: broadcast), so that the pass's kernel arguments never change

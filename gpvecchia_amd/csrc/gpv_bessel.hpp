@@ -9,6 +9,13 @@
 //   gam1(mu) = (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu),   gam2(mu) = (1/Gamma(1-mu) + 1/Gamma(1+mu)) / 2,
 // are even in mu; they are evaluated from degree-8 polynomials in mu^2 (Chebyshev interpolants on
 // [0, 1/4] computed with 60-digit arithmetic, max abs error 2.5e-22 / 2.9e-21).
+//
+// Lineage: this two-regime scheme (Temme series below x = 2, Steed's CF2 above, shared quantities named gam1, gam2,
+// gampl, gammi) is the classical one; its best-known presentation is the routine `bessik` of Press, Teukolsky,
+// Vetterling & Flannery, "Numerical Recipes" (2nd ed., sect. 6.7), whose variable naming bessel_k_nu below follows.
+// Nothing of the reference's tree is involved (it calls Boost).  The code here is a restatement of the two published
+// papers' recurrences with its own Gamma-function auxiliaries (the polynomials above) and its own table/Chebyshev layer
+// (MaternTab); acknowledged here because the structure is recognisably that of the textbook routine.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>

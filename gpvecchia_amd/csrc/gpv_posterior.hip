@@ -55,6 +55,11 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     const int qb = c0.w, qe = c1.x;                  // row list of k: columns ascending, first is k itself
     double2 *Ck = A.C + c0.y;                        // the column's own block
     const double dk = Ck[cnt].x;
+    // everything the epilogue needs is requested now, in the same round trip as the row-list records, instead of one
+    // more dependent trip after the rounds (the kernel is bound by the number of dependent memory trips per wave)
+    const double bk_own = (lane < cnt) ? Ck[1 + lane].x : 0.0;
+    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
+    const double zk = A.z[k];
     const int col = lane >> 2, sub = lane & (kSub - 1);
     // row-sum ownership: up to 32 rows -> two lanes per row (8 columns each), else one lane per row
     const bool two = A.ld <= 32;
@@ -143,13 +148,12 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
             s += part[v][65];
         }
     }
-    if (lane < cnt) acc = __builtin_fma(Ck[1 + lane].x, dk, acc);      // c == k term: B_ik d_k
-    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
+    if (lane < cnt) acc = __builtin_fma(bk_own, dk, acc);             // c == k term: B_ik d_k
     const double accd = __shfl(acc, cnt - 1, 64) + 1.0 / tau;
     const double rkk = sqrt(accd);
     if (lane < cnt) Ck[1 + lane].y = (lane == cnt - 1) ? rkk : acc / rkk;
     if (lane == 0) {
-        z2 -= A.z[k] / tau;                          // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
+        z2 -= zk / tau;                              // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
         const double t = (z2 - s) / rkk;
         Ck[0].y = t;
         A.tvec[k] = t;

@@ -211,6 +211,19 @@ __device__ __forceinline__ double rcp_pivot(double x)
     return r;
 }
 
+// the same without the exponent clamp, for the DPP sweeps: there the diagonal is clamped at 2^990 when the block is
+// loaded (pivots are Schur complements, never above their diagonal entry), which costs 3 instructions per row slot
+// instead of 3 per pivot
+__device__ __forceinline__ double rcp_pivot_bounded(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
 // sqrt(x), x > 0 normal: v_rsq_f64 seed + one coupled Goldschmidt step + one residual step
 // (error ~1 ulp; x == 0 gives NaN, callers select the dist==0 value separately).
 __device__ __forceinline__ double sqrt_pos(double x)
@@ -633,6 +646,9 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             if constexpr (COV == COV_DENSE) diag = valid[q] ? A.covvals[(int64_t)idx[q] * A.nlocs + idx[q]] : 1.0;
             else diag = valid[q] ? (sig0 + nugraw[q] * (1.0 - (double)cnd[q])) : 1.0;   // src/U_NZentries.cpp:47,52
             if (poison[q]) diag = __builtin_nan("");
+            // an Inf (or absurdly large) nugget behaves like 2^990: its multipliers vanish below rounding either way, and
+            // no pivot (a Schur complement, at most its diagonal entry) can then overflow the reciprocal; NaN stays NaN
+            diag = (diag > 0x1p990) ? 0x1p990 : diag;
             if (lane_on && row[q] < P) {
                 L.tri[sub][(int)(__umul24(row[q], row[q] + 1) >> 1) + row[q]] = diag;
                 // data row: z_j of the neighbours conditioned on as observations (R/vecchia_likelihood.R:74)
@@ -652,7 +668,13 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             const double *colB = &L.tri[sub][rc];
 #pragma unroll
             for (int c = 0; c < P; ++c) {
-                const double *src = (r >= c) ? (rowA + c) : (colB + c * (c + 1) / 2);
+                // r = i + q LPS with 0 <= i < LPS: columns left of the slot's diagonal block lie in the row part of the
+                // triangle for every lane, columns right of it in the column part; only inside the block does it depend
+                // on the lane (spare slots, r >= P, were pointed at their staged row above and sit in the last block)
+                const double *src;
+                if (c < q * LPS) src = rowA + c;
+                else if (c >= (q + 1) * LPS) src = colB + c * (c + 1) / 2;
+                else src = (r >= c) ? (rowA + c) : (colB + c * (c + 1) / 2);
                 a[q][c] = *src;
             }
         }
@@ -686,7 +708,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     }
                     pj = dpp_row_bcast<j % 16>((j % 32) < 16 ? ylo[qj] : yhi[qj], ylo[0], yhi[0], ylo[RPL - 1], yhi[RPL - 1]);
                 }
-                const double rinv = rcp_pivot(pj);
+                const double rinv = rcp_pivot_bounded(pj);
                 const bool isp = (i == j % LPS);
                 prinv[qj] = isp ? rinv : prinv[qj];
                 double nw[RPL];

@@ -155,8 +155,8 @@ int gpv_plan_set_data(gpv_plan *plan, const double *z_ord);
  * Asynchronous on `stream` (a hipStream_t; NULL selects the plan's own non-blocking stream, NOT the HIP
  * null stream: pass the stream your consumer of d_sums_out runs on); results are valid after that stream
  * is synchronised or after a blocking getter.  With a general Matern smoothness (nu not in {0.5, 1.5, 2.5}) the call
- * first waits for the work already queued on `stream` (it rebuilds the plan's host table of s^nu K_nu(s)), then
- * enqueues asynchronously as usual.
+ * spends ~1 ms on the host fitting the table of s^nu K_nu(s) for this nu before it enqueues; it does not wait for the
+ * stream (the table is double buffered).
  * If d_sums_out != NULL the GPV_NSUMS partial sums are ALSO written to that
  * device address (caller-owned, e.g. the buffer an RCCL all-reduce works on). */
 int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms,

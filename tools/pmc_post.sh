@@ -1,25 +1,32 @@
-# Developer tool: HBM traffic counters of the posterior-pass level kernels (one PMC pass, no tracing).
+# Developer tool: PMC counters of the posterior-pass level kernels (separate passes, no tracing), mode S of bench.py.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/pmc_post
-# FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950 (and a refused counter set leaves the process hanging: keep the timeouts)
-timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE FETCH_SIZE --output-format csv -d gpurun_out/pmc_post/p1 -- python3 tools/kbench.py --child --configs 30x2 --sgv --iters 1 > gpurun_out/pmc_post/log1.txt 2>&1
-timeout 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/pmc_post/p2 -- python3 tools/kbench.py --child --configs 30x2 --sgv --iters 1 > gpurun_out/pmc_post/log2.txt 2>&1
+OUT=gpurun_out/pmc_post; mkdir -p $OUT
+i=0
+for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+         "GRBM_GUI_ACTIVE FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE"; do
+  i=$((i+1))
+  GPV_NO_GRAPH=1 timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 bench.py --mode S --steps 2 --warmup 1 > $OUT/log$i.txt 2>&1
+done
 python3 - <<'PY'
-import csv, glob, collections
-for p in ("p1", "p2"):
-    for f in glob.glob(f"gpurun_out/pmc_post/{p}/**/*counter_collection.csv", recursive=True):
+import csv, glob, collections, json
+res = {}
+for p in range(1, 6):
+    for f in glob.glob(f"gpurun_out/pmc_post/p{p}/**/*counter_collection.csv", recursive=True):
         rows = list(csv.DictReader(open(f)))
-        # last evaluation: dispatches after the last conditioning-set kernel
-        disp = sorted({int(r["Dispatch_Id"]) for r in rows})
         last_sets = max(int(r["Dispatch_Id"]) for r in rows if "gpv_sets_kernel" in r["Kernel_Name"])
-        agg = collections.defaultdict(float); per = collections.defaultdict(dict)
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        order = []
         for r in rows:
             d = int(r["Dispatch_Id"])
-            if d > last_sets and "posterior_level" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]] += float(r["Counter_Value"])
-                per[d][r["Counter_Name"]] = float(r["Counter_Value"])
-        print(p, dict(agg))
-        ds = sorted(per)
-        for i in (0, 1, 2, 5, 10, 20, 40):
-            if i < len(ds): print("  level", i, per[ds[i]])
+            if d > last_sets and "posterior_le" in r["Kernel_Name"]:
+                if d not in order: order.append(d)
+                per[d][r["Counter_Name"]] += float(r["Counter_Value"])
+                per[d]["_kernel"] = r["Kernel_Name"][:60]
+                per[d]["_grid"] = r.get("Grid_Size", "")
+        for li, d in enumerate(sorted(order)):
+            res.setdefault(li, {}).update({k: v for k, v in per[d].items()})
+json.dump(res, open("gpurun_out/pmc_post/levels_pmc.json", "w"), indent=0)
+for li in (0, 1, 2, 4, 8, 12, 16, 24, 32, 48, 64, 96, 128):
+    if li in res: print(li, {k: (round(v) if isinstance(v, float) else v) for k, v in res[li].items()})
 PY
