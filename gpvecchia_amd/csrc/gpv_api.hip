@@ -254,6 +254,7 @@ struct gpv_plan {
     double nug_scalar = 0.0;
     bool nug_is_scalar = true;
     uint8_t *d_cond = nullptr;
+    std::vector<int32_t> h_newpos;  // host copy of d_newpos (shared with the sibling plans of a gpv_mplan)
     bool generic = false;          // row length > 64 or dimension > 8: workgroup-per-set kernel (gpv_sets_generic.hip)
     // Vecchia-Laplace state (gpv_plan_vl_begin): data z, prior mean, two latent-mean buffers (current / next), flags + max
     double *d_vl_z = nullptr, *d_vl_pm = nullptr, *d_vl_y[2] = {nullptr, nullptr}, *d_vl_out = nullptr;
@@ -338,8 +339,21 @@ struct PhaseTimer {
     }
 };
 
+// shared_newpos: the internal (Morton) position of every location as computed by an earlier plan of the same locations
+// (gpv_mplan_create builds one plan per device; the order depends on the locations only), or nullptr
+static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncolNN, const double *locs,
+                            const int *revNN, const int *revCond, int64_t row_begin, int64_t row_end,
+                            const int32_t *shared_newpos);
+
 int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncolNN, const double *locs,
                     const int *revNN, const int *revCond, int64_t row_begin, int64_t row_end)
+{
+    return plan_create_impl(out, device, Nlocs, dim, ncolNN, locs, revNN, revCond, row_begin, row_end, nullptr);
+}
+
+static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncolNN, const double *locs,
+                            const int *revNN, const int *revCond, int64_t row_begin, int64_t row_end,
+                            const int32_t *shared_newpos)
 {
     PhaseTimer tm;
     if (!out) return GPV_ERR_BAD_ARG;
@@ -383,7 +397,9 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     // neighbours of a point are spatially close, so their 32-byte records then share cache lines instead of
     // costing one fabric request each (profiles/: FETCH_SIZE per launch).
     std::vector<int32_t> newpos((size_t)Nlocs);
-    {
+    if (shared_newpos) {
+        std::memcpy(newpos.data(), shared_newpos, sizeof(int32_t) * (size_t)Nlocs);
+    } else {
         std::vector<uint64_t> key((size_t)Nlocs, 0);
         if (locs) {
             const int kd = dim < 3 ? dim : 3;
@@ -532,6 +548,7 @@ int gpv_plan_create(gpv_plan **out, int device, int64_t Nlocs, int dim, int ncol
     if (hipMemcpy(pl->d_newpos, newpos.data(), sizeof(int32_t) * (size_t)Nlocs, hipMemcpyHostToDevice) != hipSuccess)
         return fail(GPV_ERR_HIP);
     tm.lap("plan: alloc + H2D");
+    pl->h_newpos.swap(newpos);
     *out = pl;
     return GPV_OK;
 }
@@ -1358,7 +1375,8 @@ int gpv_mplan_create(gpv_mplan **out, const int *devices, int ndev, int64_t Nloc
     for (int g = 0; g < ndev; ++g) {
         gpv_plan *pl = nullptr;
         const int64_t a = (Nlocs * g) / ndev, b = (Nlocs * (g + 1)) / ndev;     // rows beyond the first m cost the same
-        const int rc = gpv_plan_create(&pl, devices[g], Nlocs, dim, ncolNN, locs, revNN, revCond, a, b);
+        const int rc = plan_create_impl(&pl, devices[g], Nlocs, dim, ncolNN, locs, revNN, revCond, a, b,
+                                        mp->plans.empty() ? nullptr : mp->plans[0]->h_newpos.data());   // Morton order: once
         if (rc != GPV_OK) {
             for (gpv_plan *q : mp->plans) gpv_plan_destroy(q);
             delete mp;

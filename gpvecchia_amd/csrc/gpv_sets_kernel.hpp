@@ -424,7 +424,18 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     int acc_fail = 0, acc_rows = 0;                    // sums[6], sums[7]
 
     const int64_t ntasks = (A.rows + SPW - 1) / SPW;
-    for (int64_t task = (int64_t)blockIdx.x * W + wv; task < ntasks; task += (int64_t)gridDim.x * W) {
+    // XCD-aware task order.  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2 (observed
+    // dispatch behaviour: it only steers speed, any placement computes the same sets).  The sets are stored in Morton
+    // order of their own point, so XCD x = blockIdx % 8 takes the x-th contiguous eighth of the tasks: the 32-byte
+    // location records one L2 serves then come from one eighth of the domain instead of all of it.
+#ifndef GPV_XCD_AWARE
+#define GPV_XCD_AWARE 1
+#endif
+    const int nx = (GPV_XCD_AWARE && gridDim.x >= 8) ? 8 : 1;
+    const int xcd = (nx == 8) ? (int)(blockIdx.x & 7) : 0, jb = (nx == 8) ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int nbx = (nx == 8) ? (int)((gridDim.x - xcd + 7) >> 3) : (int)gridDim.x;     // workgroups sharing this residue
+    const int64_t task_lo = ntasks * xcd / nx, task_hi = ntasks * (xcd + 1) / nx;
+    for (int64_t task = task_lo + (int64_t)jb * W + wv; task < task_hi; task += (int64_t)nbx * W) {
         const int64_t k = task * SPW + sub;
         const bool set_on = lane_on && (k < A.rows);
         // re-materialise the lane's row index per task: otherwise hipcc hoists all P (row == j) lane masks
