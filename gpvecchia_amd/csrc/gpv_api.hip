@@ -625,7 +625,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.cov = cs.cov;
     a.flags = flags;
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
-    a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0;
+    a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0; a.mt_full = 0;
     if (cs.cov == COV_MATERN_GEN) {
         bessel_tab_fill(cs.sB, a.bt);
         static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
@@ -643,8 +643,10 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             } else {
                 GPV_HIP(hipEventSynchronize(pl->mt_ev[sl]));              // two evaluations ago: long done in steady state
             }
+            int full = 0;
             matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, pl->h_mt2[sl], &a.mt_base,
-                             &a.mt_nseg, kMaxSeg);
+                             &a.mt_nseg, kMaxSeg, &full);
+            a.mt_full = (a.mt_nseg > 0 && full) ? 1 : 0;
             if (a.mt_nseg > 0) {
                 GPV_HIP(hipMemcpyAsync(pl->d_mt2[sl], pl->h_mt2[sl], sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
                                        hipMemcpyHostToDevice, st));

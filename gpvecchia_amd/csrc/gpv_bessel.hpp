@@ -257,15 +257,19 @@ struct MaternTab {
     static constexpr int DEG = 12, ROW = 16;
 };
 
+// *full (may be nullptr): 1 when [smin, smax] lies inside the tabulated range (nothing was cut at either end)
 inline void matern_tab_build(double nu, double smin, double smax, double *rows /* nseg x 16 */, int *base_idx, int *nseg,
-                             int max_seg)
+                             int max_seg, int *full = nullptr)
 {
+    if (full) *full = 0;
     constexpr int N = MaternTab::DEG + 1;
     int e_lo = (int)std::floor(std::log2(smin)), e_hi = (int)std::floor(std::log2(smax));
-    if (e_lo < -200) e_lo = -200;
-    if (e_hi > 8) e_hi = 8;                                   // s < 512: K_nu(s) e^s stays in range; beyond, the value is ~0 anyway
+    bool cut = false;
+    if (e_lo < -200) { e_lo = -200; cut = true; }
+    if (e_hi > 8) { e_hi = 8; cut = true; }                   // s < 512: K_nu(s) e^s stays in range; beyond, the value is ~0 anyway
     if (e_hi < e_lo) { *nseg = 0; *base_idx = 0; return; }
-    if ((e_hi - e_lo + 1) * 4 > max_seg) e_lo = e_hi + 1 - max_seg / 4;
+    if ((e_hi - e_lo + 1) * 4 > max_seg) { e_lo = e_hi + 1 - max_seg / 4; cut = true; }
+    if (full) *full = cut ? 0 : 1;
     *base_idx = (e_lo + 1023) << 2;
     *nseg = (e_hi - e_lo + 1) * 4;
     double cs[N][N];

@@ -43,6 +43,7 @@ struct SetArgs {
     BesselTab bt;            // COV_MATERN_GEN: order-dependent constants of K_nu (gpv_bessel.hpp), filled on the host
     const double *mt;        // COV_MATERN_GEN: [mt_nseg][16] table of s^nu K_nu(s) e^s (device), or nullptr
     int mt_base, mt_nseg;    //   segment of s = (bits(s) >> 50) - mt_base
+    int mt_full;             //   1: the table covers every pair distance of the plan (no range test per pair needed)
 };
 
 // launch the conditioning-set kernel compiled for row length P (one of gpv_plist.h); the grid is chosen from

@@ -342,6 +342,33 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
     return matern_general_tab(bt, s, normcon, nu);
 }
 
+// the same when the host has vouched that the table covers every pair distance of the plan (SetArgs::mt_full): no
+// per-lane range test, hence no divergent branch in the covariance rounds; the segment index is clamped only so that a
+// NaN / zero distance (whose value is discarded by the caller's dist == 0 select or poisons the block anyway) reads
+// inside the table
+__device__ __forceinline__ double matern_table_only(const double *mt, int mt_base, int mt_nseg, double s, double normcon)
+{
+    int seg = (int)(__double_as_longlong(s) >> 50) - mt_base;
+    seg = seg < 0 ? 0 : (seg >= mt_nseg ? mt_nseg - 1 : seg);
+    const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
+    const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6], q7 = row[7];
+    const double u = (s - q0.x) * q0.y, u2 = u + u;
+    double b2 = 0.0, b1 = q7.x, b0;
+    b0 = __builtin_fma(u2, b1, q6.y) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q6.x) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q5.y) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q5.x) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q4.y) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q4.x) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q3.y) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q3.x) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q2.y) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q2.x) - b2; b2 = b1; b1 = b0;
+    b0 = __builtin_fma(u2, b1, q1.y) - b2; b2 = b1; b1 = b0;
+    const double p = __builtin_fma(u, b1, q1.x) - b2;
+    return normcon * p * exp_neg(s);
+}
+
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
 // (src/Matern.cpp:35,48,63; src/Esqe.cpp:30-31)
 template <int COV>
@@ -370,10 +397,14 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // the same for the closed-form families without the dist == 0 select (5 VALU ops per pair): the squared distance
 // is clamped at the smallest normal number instead, where every closed form returns sigma^2 exactly
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
-template <int COV>
+template <int COV, bool TAB = false>
 __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
                                              const SetArgs &A)
 {
+    if constexpr (COV == COV_MATERN_GEN && TAB) {
+        const double v = matern_table_only(A.mt, A.mt_base, A.mt_nseg, sqrt_pos(__builtin_fmax(r2, 2.2250738585072014e-308)) * cA, sA);
+        return (r2 == 0.0) ? sig0 : v;                               // src/Matern.cpp:76
+    }
     if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
     r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
     const double dist = sqrt_pos(r2);
@@ -568,8 +599,9 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         // round and the body is one basic block (loads of the next pair overlap the arithmetic of this one).
         // Addresses: with rt = r(r+1)/2 the pair (r, r+s) lives at rt + r(s+1) + s(s+1)/2 if r+s < P, else (it wraps
         // to j = r+s-P < r) at rt + j; the constant s(s+1)/2 rides in the instruction's offset field.
-        auto cov_rounds_fast = [&](auto masked_tag) {
+        auto cov_rounds_fast = [&](auto masked_tag, auto tab_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
+            constexpr bool TAB = decltype(tab_tag)::value;           // general nu: table-only evaluation (no per-pair range test)
             constexpr int DS = Lds::DS, DD = (D == 0) ? 1 : D;
             // 32-bit byte offsets inside the set's LDS slices (24-bit multiplies: one v_mad_u32_u24 per address)
             const char *xyb = reinterpret_cast<const char *>(&L.xy[sub][0][0]);
@@ -620,7 +652,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV>(r2, sig0, sA, cA, sB, cB, A);
+                    v[q] = cov_closed<COV, TAB>(r2, sig0, sA, cA, sB, cB, A);
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;
@@ -642,8 +674,18 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             }
         };
         if constexpr (D != 0 && COV != COV_DENSE) {
-            if (all_valid) cov_rounds_fast(std::false_type{});   // wave-uniform: the common case has no padding
-            else cov_rounds_fast(std::true_type{});
+            if constexpr (COV == COV_MATERN_GEN) {
+                if (A.mt_full) {                                 // kernel argument: uniform
+                    if (all_valid) cov_rounds_fast(std::false_type{}, std::true_type{});
+                    else cov_rounds_fast(std::true_type{}, std::true_type{});
+                } else {
+                    if (all_valid) cov_rounds_fast(std::false_type{}, std::false_type{});
+                    else cov_rounds_fast(std::true_type{}, std::false_type{});
+                }
+            } else {
+                if (all_valid) cov_rounds_fast(std::false_type{}, std::false_type{});   // wave-uniform: the common case has no padding
+                else cov_rounds_fast(std::true_type{}, std::false_type{});
+            }
         } else {
             if (all_valid) cov_rounds(std::false_type{});
             else cov_rounds(std::true_type{});

@@ -1,0 +1,99 @@
+"""Randomised shapes and repeated launches: the register-resident sweeps exchange operands by inline-asm DPP /
+permlane instructions whose hazards hipcc cannot see, so beyond the fixed parity cases this file (a) walks seeded random
+combinations of row length, dimension, covariance family, conditioning mode and nugget layout against the oracle and
+(b) replays the same launch many times at sizes that fill the chip, asserting bit-identical outputs (a missed wait state
+shows up as a rare, placement-dependent difference)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    import gpvecchia_amd as G
+    if G.device_count() < 1:
+        pytest.fail("gpu-marked test but libgpvecchia_hip sees no HIP device")
+    return G
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_against_oracle(seed):
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(7000 + seed)
+    m = int(rng.choice([1, 2, 3, 5, 7, 9, 10, 11, 14, 15, 16, 19, 20, 22, 25, 27, 30, 31, 33, 38, 40, 44, 47, 48, 50, 55, 60, 63]))
+    d = int(rng.choice([1, 2, 2, 3, 3, 4, 6]))
+    cond = str(rng.choice(["z", "SGV", "y"]))
+    fam = int(rng.integers(0, 5))
+    n = int(rng.integers(max(m + 5, 150), 700))
+    locs = rng.random((n, d))
+    if rng.random() < 0.3:                                            # a few exact duplicates (dist == 0 -> sigma^2 exactly)
+        dup = rng.choice(np.arange(1, n), size=5, replace=False)
+        locs[dup] = locs[dup - 1]
+        cond = "z"
+    z = rng.standard_normal(n)
+    NN = R.findOrderedNN(locs, m)
+    va = R.vecchia_specify(locs, m, ordering="none", cond_yz=cond, NNarray=NN)
+    rg = (0.15 + 0.3 * rng.random()) * (np.sqrt(d) if d > 1 else 0.02)
+    if fam == 4:
+        covmodel, cp = "esqe", [0.7 + rng.random(), rg, 0.2 + 0.5 * rng.random(), 0.5 * rg]
+    else:
+        covmodel, cp = "matern", [0.5 + 2 * rng.random(), rg, [0.5, 1.5, 2.5, 0.3 + 2.0 * rng.random()][fam]]
+        if cond != "z" and cp[2] > 1.6:
+            cp[2] = 1.5                                               # smooth kernels + latent conditioning: singular to working precision
+    tau = (0.05 + rng.random(n)) if rng.random() < 0.5 else np.full(n, 0.05 + rng.random())
+    ref = R.createU(va, cp, tau, covmodel)
+    prep = va["U_prep"]
+    out = G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], tau, tau, covmodel, cp)
+    assert out["n_failed"] == ref["U_entries"]["n_failed"]
+    L0, L1 = ref["U_entries"]["Lentries"], out["Lentries"]
+    np.testing.assert_array_equal(L1 == 0, L0 == 0)
+    covfun = R.EsqeFun if covmodel == "esqe" else R.MaternFun
+    eps = np.finfo(float).eps
+    for k in range(n):
+        err = np.abs(L1[k] - L0[k]).max() / max(np.abs(L0[k]).max(), 1e-300)
+        if err > 1e-10:
+            ok = ~np.isnan(prep["revNNarray"][k])
+            idx = prep["revNNarray"][k][ok].astype(int) - 1
+            S = covfun(R.rdist(locs[idx]), cp) + np.diag(tau[idx] * (1 - prep["revCond"][k][ok]))
+            assert err <= 32 * np.linalg.cond(S) * eps, (seed, m, d, cond, covmodel, k, err)
+    np.testing.assert_allclose(out["Zentries"], ref["U_entries"]["Zentries"], rtol=1e-15)
+    if ref["U_entries"]["n_failed"] == 0:
+        prod = dict(va)
+        pp = dict(prep)
+        pp["revNNarray"] = np.nan_to_num(prep["revNNarray"]).astype(np.int32)
+        pp["revCond"] = np.nan_to_num(prep["revCond"], nan=-1.0).astype(np.int8)
+        prod["U_prep"] = pp
+        ll_ref = R.vecchia_likelihood_U(z, ref)
+        ll = G.vecchia_likelihood(z, prod, cp, tau, covmodel)
+        assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref) + 1e-9, (seed, m, d, cond, covmodel)
+
+
+@pytest.mark.parametrize("m,d,n", [(30, 2, 400_000), (60, 3, 120_000), (40, 2, 200_000), (15, 2, 400_000), (20, 2, 400_000),
+                                   (10, 2, 400_000), (47, 3, 150_000), (63, 2, 120_000)])
+def test_repeated_launches_are_bit_identical(m, d, n):
+    # every register-exchange geometry at a size that fills all 256 CUs several times over, 25 launches each
+    G = _need_gpu()
+    from gpvecchia_amd import specify as S
+    rng = np.random.default_rng(m * 100 + d)
+    locs = rng.random((n, d))
+    z = rng.standard_normal(n)
+    NN = S.find_ordered_nn_gpu(locs, m)
+    revNN = NN[:, ::-1].copy()
+    revCond = S.whichCondOnLatent(NN)[:, ::-1].copy()
+    plan = G.Plan(locs, revNN, revCond)
+    plan.set_data(z)
+    tau = 0.05 + rng.random(n)
+    cp = [1.0, 0.5 * (1.0 / n) ** (1.0 / d) * 8, 1.5 if m < 45 else 0.5]
+    flags = G.GPV_WANT_U | G.GPV_WANT_NUMERATOR | G.GPV_WANT_LOGLIK_Z
+    plan.eval("matern", cp, tau, flags)
+    s0 = plan.sums().copy()
+    dptr, ld = plan.Lentries_device()
+    L0 = plan.Lentries().copy()
+    assert s0[7] == n and np.isfinite(L0).all()
+    for it in range(25):
+        plan.eval("matern", cp, tau, flags)
+        s = plan.sums()
+        assert np.array_equal(s, s0), (it, s - s0)
+        if it % 8 == 7:
+            assert np.array_equal(plan.Lentries(), L0), it
