@@ -245,6 +245,7 @@ struct gpv_plan {
     double *d_nug_post = nullptr;                    // [Nlocs] nuggets in ordering: fixed kernel argument for the graph
     // general-nu Matern: range of pair distances of the plan (parameter independent) and the per-evaluation table
     double dist_min = 0.0, dist_max = 0.0;
+    std::vector<int64_t> dist_hist;                  // point-to-neighbour distances by binary exponent (index = exponent + 1100)
     double *h_mt2[2] = {nullptr, nullptr}, *d_mt2[2] = {nullptr, nullptr};   // pinned staging / device copies, used alternately
     hipEvent_t mt_ev[2] = {nullptr, nullptr};
     int mt_slot = 0, mt_pending = -1;
@@ -498,8 +499,10 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
     if (locs) {
         std::mutex mu_;
         double gmin = INFINITY, gmax = 0.0;
+        pl->dist_hist.assign(2200, 0);
         parallel_for(Nlocs, [&](int64_t b, int64_t e) {
             double lmin = INFINITY, lmax = 0.0;
+            std::vector<int64_t> lh(2200, 0);
             for (int64_t k = b; k < e; ++k) {
                 const int self = revNN[k + (int64_t)(ncolNN - 1) * Nlocs];
                 if (is_missing(self) || self < 1 || (int64_t)self > Nlocs) continue;
@@ -514,11 +517,16 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
                     const double dd = std::sqrt(r2);
                     if (dd > lmax) lmax = dd;                    // first valid entry is the farthest, but rows need not be sorted
                     if (dd > 0.0 && dd < lmin) lmin = dd;
+                    if (dd > 0.0 && std::isfinite(dd)) {
+                        int ex = std::ilogb(dd) + 1100;
+                        lh[(size_t)(ex < 0 ? 0 : (ex > 2199 ? 2199 : ex))]++;
+                    }
                 }
             }
             std::lock_guard<std::mutex> g(mu_);
             if (lmin < gmin) gmin = lmin;
             if (lmax > gmax) gmax = lmax;
+            for (size_t t = 0; t < lh.size(); ++t) pl->dist_hist[t] += lh[t];
         });
         pl->dist_min = std::isfinite(gmin) ? gmin : 0.0;
         pl->dist_max = gmax;
@@ -625,7 +633,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.cov = cs.cov;
     a.flags = flags;
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
-    a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0; a.mt_full = 0;
+    a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0; a.mt_full = 0; a.mt_win = 0;
     if (cs.cov == COV_MATERN_GEN) {
         bessel_tab_fill(cs.sB, a.bt);
         static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
@@ -647,6 +655,29 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, pl->h_mt2[sl], &a.mt_base,
                              &a.mt_nseg, kMaxSeg, &full);
             a.mt_full = (a.mt_nseg > 0 && full) ? 1 : 0;
+            // LDS window of the kernel (gpv_sets_kernel.hpp, mt_window_rows): the 6 octaves of s = dist/range that hold most of
+            // the plan's point-to-neighbour distances, shifted up half an octave for the neighbour-to-neighbour pairs
+            a.mt_win = 0;
+            if (a.mt_full && !pl->dist_hist.empty()) {
+                const int e_lo = (a.mt_base >> 2) - 1023;                 // binary exponent of the table's first segment
+                const int noct = a.mt_nseg / 4;
+                const double sh = std::log2(cs.cA) + 0.5;
+                std::vector<double> H((size_t)noct, 0.0);
+                for (int ex = 0; ex < 2200; ++ex) {
+                    if (!pl->dist_hist[(size_t)ex]) continue;
+                    const int o = (int)std::floor((double)(ex - 1100) + sh) - e_lo;
+                    if (o >= 0 && o < noct) H[(size_t)o] += (double)pl->dist_hist[(size_t)ex];
+                }
+                double best = -1.0;
+                int bo = 0;
+                for (int o = 0; o + 6 <= noct || o == 0; ++o) {
+                    double m6 = 0.0;
+                    for (int t = 0; t < 6 && o + t < noct; ++t) m6 += H[(size_t)(o + t)];
+                    if (m6 > best) { best = m6; bo = o; }
+                    if (o + 6 > noct) break;
+                }
+                a.mt_win = 4 * bo;
+            }
             if (a.mt_nseg > 0) {
                 GPV_HIP(hipMemcpyAsync(pl->d_mt2[sl], pl->h_mt2[sl], sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
                                        hipMemcpyHostToDevice, st));

@@ -44,6 +44,7 @@ struct SetArgs {
     const double *mt;        // COV_MATERN_GEN: [mt_nseg][16] table of s^nu K_nu(s) e^s (device), or nullptr
     int mt_base, mt_nseg;    //   segment of s = (bits(s) >> 50) - mt_base
     int mt_full;             //   1: the table covers every pair distance of the plan (no range test per pair needed)
+    int mt_win;              //   first table row of the window the workgroups keep in LDS (where the distances concentrate)
 };
 
 // launch the conditioning-set kernel compiled for row length P (one of gpv_plist.h); the grid is chosen from

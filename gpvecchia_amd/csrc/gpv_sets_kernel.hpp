@@ -162,7 +162,8 @@ struct SetsLds {
     static constexpr int COLS0 = (G::SLOTS + 2) & ~1;
     static constexpr int COLS = ((COLS0 * 8) % 256 == 0) ? COLS0 + 2 : COLS0;
     double tri[SPW][TRI];        // packed lower triangle (diagonal included): (hi,lo) at hi(hi+1)/2+lo
-    double col[2][SPW][COLS];    // pivot-row exchange, double buffered; col[1] doubles as the data-row staging
+    static constexpr int NCOL = G::DPP ? 1 : 2;
+    double col[NCOL][SPW][COLS]; // LDS sweep: pivot-row exchange, double buffered; the last one doubles as the data-row staging
     double xy[SPW][P][DS];       // staged coordinates
     static constexpr bool NEEDZERO = G::SLOTS > P + (G::ZROW ? 1 : 0);
     double zero[NEEDZERO ? COLS : 2];   // source of the padding rows beyond the data row
@@ -181,6 +182,22 @@ constexpr int blocks_per_cu()
     const int by_lds = (int)(163840 / (sizeof(SetsLds<P, D, COV>) * w));
     const int cap = 8 / w;                          // 2 waves per SIMD
     return by_lds < cap ? (by_lds < 1 ? 1 : by_lds) : cap;
+}
+// General-nu Matern: rows of the per-launch table of s^nu K_nu(s) e^s kept in LDS by every workgroup (a WINDOW of whole
+// octaves chosen by the host where the plan's pair distances concentrate).  From global memory the 8 x 16-byte row
+// gathers per pair make the kernel texture-address bound (5.2 ms against 1.55 ms for a closed form at n = 1e6, m = 30);
+// the window takes exactly the LDS the instantiation leaves unused at its occupancy, so it never costs a workgroup.
+constexpr int kMtRowLds = 18;                       // doubles per LDS row: 144-byte stride => 16 distinct rows hit 16 distinct bank quads
+template <int P, int D, int COV>
+constexpr int mt_window_rows()
+{
+    if (COV != COV_MATERN_GEN || D == 0) return 0;
+    const int w = wpb<P, D, COV>();
+    const long left = 163840 / blocks_per_cu<P, D, COV>() - (long)sizeof(SetsLds<P, D, COV>) * w - 64;
+    long rows = left / (kMtRowLds * 8);
+    rows = rows > 32 ? 32 : rows;
+    rows &= ~3L;                                    // whole octaves
+    return rows < 8 ? 0 : (int)rows;
 }
 
 // Lanes of one wavefront exchange data through LDS.  The hardware executes a wave's LDS
@@ -346,12 +363,27 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
 // per-lane range test, hence no divergent branch in the covariance rounds; the segment index is clamped only so that a
 // NaN / zero distance (whose value is discarded by the caller's dist == 0 select or poisons the block anyway) reads
 // inside the table
-__device__ __forceinline__ double matern_table_only(const double *mt, int mt_base, int mt_nseg, double s, double normcon)
+template <int MTW>
+__device__ __forceinline__ double matern_table_only(const double *mt, int mt_base, int mt_nseg, int mt_win, const double *mt_lds,
+                                                    double s, double normcon)
 {
     int seg = (int)(__double_as_longlong(s) >> 50) - mt_base;
     seg = seg < 0 ? 0 : (seg >= mt_nseg ? mt_nseg - 1 : seg);
-    const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
-    const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6], q7 = row[7];
+    double2 q0, q1, q2, q3, q4, q5, q6, q7;
+    bool from_lds = false;
+    if constexpr (MTW > 0) {
+        const int rel = seg - mt_win;
+        const bool in = (unsigned)rel < (unsigned)MTW;
+        if (__builtin_amdgcn_ballot_w64(!in) == 0) {                // wave uniform: every lane's segment sits in the LDS window
+            const double2 *row = reinterpret_cast<const double2 *>(mt_lds + rel * kMtRowLds);
+            q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5]; q6 = row[6]; q7 = row[7];
+            from_lds = true;
+        }
+    }
+    if (!from_lds) {
+        const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
+        q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5]; q6 = row[6]; q7 = row[7];
+    }
     const double u = (s - q0.x) * q0.y, u2 = u + u;
     double b2 = 0.0, b1 = q7.x, b0;
     b0 = __builtin_fma(u2, b1, q6.y) - b2; b2 = b1; b1 = b0;
@@ -397,12 +429,13 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // the same for the closed-form families without the dist == 0 select (5 VALU ops per pair): the squared distance
 // is clamped at the smallest normal number instead, where every closed form returns sigma^2 exactly
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
-template <int COV, bool TAB = false>
+template <int COV, bool TAB = false, int MTW = 0>
 __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
-                                             const SetArgs &A)
+                                             const SetArgs &A, const double *mt_lds = nullptr)
 {
     if constexpr (COV == COV_MATERN_GEN && TAB) {
-        const double v = matern_table_only(A.mt, A.mt_base, A.mt_nseg, sqrt_pos(__builtin_fmax(r2, 2.2250738585072014e-308)) * cA, sA);
+        const double v = matern_table_only<MTW>(A.mt, A.mt_base, A.mt_nseg, A.mt_win, mt_lds,
+                                                sqrt_pos(__builtin_fmax(r2, 2.2250738585072014e-308)) * cA, sA);
         return (r2 == 0.0) ? sig0 : v;                               // src/Matern.cpp:76
     }
     if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
@@ -431,6 +464,18 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     using Lds = SetsLds<P, D, COV>;
     constexpr int COLS = Lds::COLS;
     __shared__ Lds lds_all[W];
+    constexpr int MTW = mt_window_rows<P, D, COV>();
+    __shared__ __attribute__((aligned(16))) double mt_lds[MTW > 0 ? MTW * kMtRowLds : 2];
+    if constexpr (MTW > 0) {
+        if (A.mt_full) {                                 // rows [mt_win, mt_win + MTW) of this launch's table (clamped at its end)
+            for (int t = threadIdx.x; t < MTW * 8; t += W * 64) {
+                const int r = t >> 3, c = t & 7;
+                const int src = (A.mt_win + r < A.mt_nseg) ? A.mt_win + r : A.mt_nseg - 1;
+                reinterpret_cast<double2 *>(mt_lds + r * kMtRowLds)[c] = reinterpret_cast<const double2 *>(A.mt + (size_t)src * MaternTab::ROW)[c];
+            }
+            __syncthreads();
+        }
+    }
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
@@ -652,7 +697,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV, TAB>(r2, sig0, sA, cA, sB, cB, A);
+                    v[q] = cov_closed<COV, TAB, MTW>(r2, sig0, sA, cA, sB, cB, A, mt_lds);
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;
@@ -705,7 +750,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             if (lane_on && row[q] < P) {
                 L.tri[sub][(int)(__umul24(row[q], row[q] + 1) >> 1) + row[q]] = diag;
                 // data row: z_j of the neighbours conditioned on as observations (R/vecchia_likelihood.R:74)
-                if (ZROW) L.col[1][sub][row[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? zi[q] : 0.0;
+                if (ZROW) L.col[Lds::NCOL - 1][sub][row[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? zi[q] : 0.0;
             }
         }
         wave_sync();
@@ -715,7 +760,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             // slot P reads the staged data row, slots beyond read zeros
             const int r = row[q];
             const int rc = r < P ? r : 0;
-            const double *extra = (ZROW && r == P) ? &L.col[1][sub][0] : &L.zero[0];
+            const double *extra = (ZROW && r == P) ? &L.col[Lds::NCOL - 1][sub][0] : &L.zero[0];
             // spare slots (r >= P) always take the "c <= r" branch below: point it at the staged row instead
             const double *rowA = (RPL * LPS > P && r >= P) ? extra : &L.tri[sub][(int)(__umul24(rc, rc + 1) >> 1)];
             const double *colB = &L.tri[sub][rc];
@@ -863,7 +908,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 negmu = negmu_z;
             } else {
                 // no spare slot: a_k = sum_j M_j z_j through LDS (R/vecchia_likelihood.R:74), -mu_k = a_k / d_k
-                double *cb = L.col[P & 1][sub];
+                double *cb = L.col[(P & 1) & (Lds::NCOL - 1)][sub];
 #pragma unroll
                 for (int q = 0; q < RPL; ++q)
                     cb[wslot[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? x[q] * zi[q] : 0.0;
