@@ -157,6 +157,8 @@ int gpv_plan_set_data(gpv_plan *plan, const double *z_ord);
  * is synchronised or after a blocking getter.  With a general Matern smoothness (nu not in {0.5, 1.5, 2.5}) the call
  * spends ~1 ms on the host fitting the table of s^nu K_nu(s) for this nu before it enqueues; it does not wait for the
  * stream (the table is double buffered).
+ * Evaluations of one plan are ordered by the stream they are enqueued on; an evaluation enqueued on a different stream
+ * than the previous one first waits (on the host) for that previous stream, because the plan's buffers are reused.
  * If d_sums_out != NULL the GPV_NSUMS partial sums are ALSO written to that
  * device address (caller-owned, e.g. the buffer an RCCL all-reduce works on). */
 int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms,
