@@ -75,8 +75,9 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
             work.append((inst, os.path.join(BUILD, f"sets_p{P}.o"), [f"-DGPV_INST_P={P}"] + extra_flags, kern, force))
     work.append((os.path.join(CSRC, "gpv_aux_kernels.hip"), os.path.join(BUILD, "aux.o"), list(extra_flags),
                  kern + H("gpv_plist.h"), force))
-    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub] + H("gpv_laplace.h", "gpv_generic.h"), force))
-    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags), internal, force))
+    work.append((os.path.join(CSRC, "gpv_api.hip"), os.path.join(BUILD, "api.o"), list(extra_flags), internal + [pub] + H("gpv_laplace.h", "gpv_generic.h", "gpv_posterior_ext.h"), force))
+    work.append((os.path.join(CSRC, "gpv_posterior.hip"), os.path.join(BUILD, "posterior.o"), list(extra_flags),
+                 internal + H("gpv_posterior_ext.h"), force))
     work.append((os.path.join(CSRC, "gpv_laplace.hip"), os.path.join(BUILD, "laplace.o"), [], H("gpv_laplace.h"), force))
     work.append((os.path.join(CSRC, "gpv_sets_generic.hip"), os.path.join(BUILD, "generic.o"), list(extra_flags),
                  kern + H("gpv_generic.h"), force))

@@ -6,6 +6,7 @@
 #include "gpv_internal.h"
 #include "gpv_laplace.h"
 #include "gpv_generic.h"
+#include "gpv_posterior_ext.h"
 
 #include <chrono>
 #include <climits>
@@ -249,7 +250,8 @@ struct gpv_plan {
     double *h_mt2[2] = {nullptr, nullptr}, *d_mt2[2] = {nullptr, nullptr};   // pinned staging / device copies, used alternately
     hipEvent_t mt_ev[2] = {nullptr, nullptr};
     int mt_slot = 0, mt_pending = -1;
-    int32_t *d_order2 = nullptr;
+    int32_t *d_order2 = nullptr, *d_levptr2 = nullptr;
+    int mean_head_levels = 0;                        // leading levels of the mean sweep run by one workgroup
     double *d_u = nullptr, *d_mu = nullptr;
     bool have_mean = false;
     double nug_scalar = 0.0;
@@ -309,7 +311,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
-                    pl->d_order2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
+                    pl->d_order2, pl->d_levptr2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -721,7 +723,9 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             if (e == hipSuccess)
                 e = launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st);
             if (want_mean) {
-                for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr2.size(); ++lv)
+                if (e == hipSuccess)
+                    e = launch_mean_head(pa, pl->d_order2, pl->d_u, pl->d_levptr2, pl->mean_head_levels, st);
+                for (size_t lv = (size_t)pl->mean_head_levels; e == hipSuccess && lv + 1 < pl->levptr2.size(); ++lv)
                     e = launch_mean_level(pa, pl->d_order2, pl->d_u, pl->levptr2[lv],
                                           pl->levptr2[lv + 1] - pl->levptr2[lv], st);
                 if (e == hipSuccess) e = launch_negate(pl->d_u, pl->d_mu, pl->Nlocs, st);
@@ -950,6 +954,13 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     GPV_HIP(hipMalloc((void **)&pl->d_C, sizeof(double2) * (nnz + (size_t)n)));
     pl->post_nnz = (int64_t)nnz;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_levptr2, pl->levptr2.data(), pl->levptr2.size() * 4)) != GPV_OK) return rc;
+    pl->mean_head_levels = 0;
+    static const bool no_head = getenv("GPV_NO_MEAN_HEAD") != nullptr;
+    while (!no_head && (size_t)pl->mean_head_levels + 1 < pl->levptr2.size() &&
+           pl->levptr2[(size_t)pl->mean_head_levels + 1] - pl->levptr2[(size_t)pl->mean_head_levels] <= kMeanHeadMax)
+        ++pl->mean_head_levels;
+    if (pl->mean_head_levels < 4) pl->mean_head_levels = 0;            // not worth a launch of its own
     const size_t nd = sizeof(double) * (size_t)n;
     if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
     if (!pl->d_nug_post) GPV_HIP(hipMalloc((void **)&pl->d_nug_post, nd));

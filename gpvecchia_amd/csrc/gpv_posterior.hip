@@ -15,6 +15,7 @@
 // Columns are level-scheduled (column k waits for every column c > k that contains row k); one wavefront
 // per column (eight for hub columns); the row/column matching is precomputed once per plan (tptr/tp).
 #include "gpv_internal.h"
+#include "gpv_posterior_ext.h"
 #include <atomic>
 
 namespace gpv {
@@ -264,6 +265,42 @@ hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u
 {
     if (count <= 0) return hipSuccess;
     hipLaunchKernelGGL(gpv_mean_level_kernel, dim3((count + 3) / 4), dim3(256), 0, s, a, order2, u, first, count);
+    return hipGetLastError();
+}
+// The first levels of the ascending schedule hold the first points of the ordering, each conditioned on (nearly) all of
+// its predecessors: ~31 levels of ONE column, then a slow widening.  One 16-wave workgroup walks them: a wave per column,
+// a workgroup barrier per level.  u written by one wave is read by others of the same workgroup in later levels: the
+// stores are drained and the barrier passed before any such load, and the loads bypass the vector L1 (agent-scope
+// relaxed atomics = sc1 loads), so neither cache can serve a value from before the store.
+__global__ void __launch_bounds__(1024) gpv_mean_head_kernel(const PostArgs A, const int32_t *order2, double *u,
+                                                             const int32_t *levptr2, int nlev)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int lv = 0; lv < nlev; ++lv) {
+        const int first = levptr2[lv], count = levptr2[lv + 1] - first;
+        for (int w = wave; w < count; w += 16) {
+            const int k = order2[first + w];
+            const int cp = A.colptr[k];
+            const int cnt = A.colptr[k + 1] - cp;
+            double part = 0.0, rkk = 1.0;
+            if (lane < cnt) {
+                const int i = A.crow[cp + lane];
+                const double r = A.C[(int64_t)cp + k + 1 + lane].y;
+                if (lane == cnt - 1) rkk = r;
+                else part = r * __hip_atomic_load(&u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+            rkk = __shfl(rkk, cnt - 1, 64);
+            if (lane == 0) u[k] = (A.tvec[k] - part) / rkk;
+        }
+        __syncthreads();                                 // drains this level's stores (vmcnt(0)) before anyone reads them
+    }
+}
+hipError_t launch_mean_head(const PostArgs &a, const int32_t *order2, double *u, const int32_t *levptr2, int nlev, hipStream_t s)
+{
+    if (nlev <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gpv_mean_head_kernel, dim3(1), dim3(1024), 0, s, a, order2, u, levptr2, nlev);
     return hipGetLastError();
 }
 __global__ void gpv_negate_kernel(const double *src, double *dst, int64_t n)
