@@ -20,6 +20,14 @@
 
 namespace gpv {
 
+// 16-byte non-temporal load of a structure record (HIP's int4 is a class; the builtin wants a native vector)
+typedef int gpv_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int4 nt_load(const int4 *p)
+{
+    const gpv_v4i v = __builtin_nontemporal_load(reinterpret_cast<const gpv_v4i *>(p));
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
 // Lanes own the COLUMNS c > k of row k's list, not the rows of column k: a hub row that is conditioned on by
 // hundreds of later points is then a sequence of wide rounds instead of one long serial merge.  A round covers
 // kRC = 16 columns with kSub = 4 lanes each (row lists average ~m/2.5 entries, so wider rounds idle most lanes
@@ -50,7 +58,10 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
     if (WPC == 1 && w >= count) return;
     double *T = tile_all + (size_t)wib * A.ld * kTS;
-    const int4 c0 = A.colrec[2 * (size_t)(first + w)], c1 = A.colrec[2 * (size_t)(first + w) + 1];
+    // the structure records are read once per evaluation: non-temporal, so that ~0.3 GB of them per pass do not push the
+    // set kernel's index stream and location records out of the Infinity Cache between evaluations
+    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
+    const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
     const int k = c0.x;
     const int cnt = c0.z;                            // latent entries of column k, ascending rows, self (= k) last
     const int qb = c0.w, qe = c1.x;                  // row list of k: columns ascending, first is k itself
@@ -73,7 +84,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
         const double2 *Cc = A.C;
         double Bk = 0.0, Rk = 0.0;
         if (q < qe) {
-            const int4 rr = A.rowrec[q];
+            const int4 rr = nt_load(&A.rowrec[q]);
             Cc = A.C + rr.x;
             const double2 head = Cc[0], own = Cc[1 + (rr.z & 255)];     // (a_c, t_c), (B_kc, R_kc)
             Bk = own.x;
@@ -96,7 +107,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
                 const int e = e0 + u * kSub;
-                const int v = (e < ne) ? (int)A.tp[tb + e] : 0xFF;
+                const int v = (e < ne) ? (int)__builtin_nontemporal_load(&A.tp[tb + e]) : 0xFF;
                 pv[u] = (v == 0xFF) ? -1 : v;            // 0xFF: the row is not in column k (never under SGV) => zero fill
             }
             double2 br[EC];                              // address known from the row-list record: issued with the match bytes
@@ -190,7 +201,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
 {
     const int w = (int)((blockIdx.x * 256 + threadIdx.x) >> 4), sub = threadIdx.x & 15;
     if (w >= count) return;
-    const int4 c0 = A.colrec[2 * (size_t)(first + w)];
+    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
     const int k = c0.x, cnt = c0.z;
     double2 *Ck = A.C + c0.y;
     const double dk = Ck[cnt].x;
