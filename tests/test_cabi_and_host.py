@@ -263,3 +263,32 @@ def test_nelder_mead_reproduces_the_known_answer_of_R_optim():
     # evaluation limit -> convergence code 1 (optim's maxit counts function evaluations for this method)
     _, _, c2, code2 = _nelder_mead_nash(fr, [-1.2, 1.0], reltol=1e-12, maxit=50)
     assert code2 == 1 and 50 < c2 <= 53
+
+
+def _build_c_caller(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "kat")
+    libdir = os.path.join(root, "gpvecchia_amd")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_abi", "kat.c"), "-o", exe, "-L", libdir, "-lgpvecchia_hip",
+                           f"-Wl,-rpath,{libdir}", "-lm"])
+    return exe
+
+
+@pytest.mark.skipif(__import__("gpvecchia_amd").device_count() > 0, reason="only meaningful without a GPU")
+def test_plain_c_caller_links_and_reports_no_device(tmp_path):
+    # include/gpvecchia.h is consumable by a C compiler and the library links into a plain C program (what R's .C() needs)
+    import subprocess
+    import gpvecchia_amd  # noqa: F401  (builds the library if missing)
+    r = subprocess.run([_build_c_caller(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 77 and "no HIP device" in r.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_caller_known_answer(tmp_path):
+    # the known-answer case of SURVEY.md §8c from a C program, through the .C()-style entry and the plan API
+    import subprocess
+    import gpvecchia_amd  # noqa: F401
+    r = subprocess.run([_build_c_caller(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "known-answer test ok" in r.stdout, r.stdout + r.stderr
