@@ -251,6 +251,8 @@ struct gpv_plan {
     hipEvent_t mt_ev[2] = {nullptr, nullptr};
     int mt_slot = 0, mt_pending = -1;
     int32_t *d_order2 = nullptr, *d_levptr2 = nullptr;
+    double *d_toppart = nullptr;                     // [top_K][66] partial sums of the top block's columns
+    int top_K = 0;                                   // columns 0 .. top_K-1 are kept out of the schedule (gpv_posterior_ext.h)
     int mean_head_levels = 0;                        // leading levels of the mean sweep run by one workgroup
     double *d_u = nullptr, *d_mu = nullptr;
     bool have_mean = false;
@@ -311,7 +313,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
-                    pl->d_order2, pl->d_levptr2, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
+                    pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -720,6 +722,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                                                     pl->Nlocs, pl->post_nnz, pl->d_C, st);
             for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr.size(); ++lv)
                 e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st);
+            if (e == hipSuccess && pl->top_K > 0)
+                e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, st);
             if (e == hipSuccess)
                 e = launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st);
             if (want_mean) {
@@ -877,10 +881,15 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
             }
         });
     }
-    // level of column k = 1 + max level of the columns c > k that contain row k
+    // the dense top block (gpv_posterior_ext.h): the first K columns of the ordering stay out of the schedule
+    // (GPV_POST_TOP=0: all columns are scheduled)
+    static const bool no_top = getenv("GPV_POST_TOP") != nullptr && atoi(getenv("GPV_POST_TOP")) == 0;
+    const int64_t K = no_top ? 0 : std::min<int64_t>(n, kTopMax);
+    pl->top_K = (int)K;
+    // level of column k >= K = 1 + max level of the columns c > k that contain row k
     std::vector<int32_t> lev((size_t)n, 0);
-    int32_t maxlev = 0;
-    for (int64_t k = n - 1; k >= 0; --k) {
+    int32_t maxlev = -1;
+    for (int64_t k = n - 1; k >= K; --k) {
         int32_t l = 0;
         for (int32_t q = rowptr[(size_t)k]; q < rowptr[(size_t)k + 1]; ++q) {
             const int32_t c = rcol[(size_t)q];
@@ -889,11 +898,12 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
         lev[(size_t)k] = l;
         if (l > maxlev) maxlev = l;
     }
-    pl->levptr.assign((size_t)maxlev + 2, 0);
-    for (int64_t k = 0; k < n; ++k) pl->levptr[(size_t)lev[(size_t)k] + 1]++;
+    pl->levptr.assign((size_t)(maxlev + 2), 0);
+    for (int64_t k = K; k < n; ++k) pl->levptr[(size_t)lev[(size_t)k] + 1]++;
     for (int32_t l = 0; l <= maxlev; ++l) pl->levptr[(size_t)l + 1] += pl->levptr[(size_t)l];
     std::vector<int32_t> pos(pl->levptr.begin(), pl->levptr.end() - 1), order((size_t)n);
-    for (int64_t k = n - 1; k >= 0; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
+    for (int64_t k = n - 1; k >= K; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
+    for (int64_t k = 0; k < K; ++k) order[(size_t)(n - K + k)] = (int32_t)k;      // the top block's records: after the schedule
     // longest row lists first inside a level (they bound the level's duration)
     for (int32_t l = 0; l <= maxlev; ++l)
         std::stable_sort(order.begin() + pl->levptr[(size_t)l], order.begin() + pl->levptr[(size_t)l + 1],
@@ -905,7 +915,11 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
         const int32_t k = order[(size_t)i];
         const int32_t b0 = colptr[(size_t)k], cn = colptr[(size_t)k + 1] - b0;
         colrec[2 * (size_t)i] = make_int4(k, b0 + k, cn, rowptr[(size_t)k]);
-        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], 0, 0, 0);
+        // .y: end of the row-list entries whose column lies in the top block (row lists ascend: a prefix)
+        int32_t qt = rowptr[(size_t)k];
+        if ((int64_t)k < K)
+            while (qt < rowptr[(size_t)k + 1] && (int64_t)rcol[(size_t)qt] < K) ++qt;
+        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], qt, 0, 0);
     }
     std::vector<int32_t> ccol(nnz);
     for (int64_t c = 0; c < n; ++c) {
@@ -955,6 +969,8 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     pl->post_nnz = (int64_t)nnz;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_levptr2, pl->levptr2.data(), pl->levptr2.size() * 4)) != GPV_OK) return rc;
+    if (pl->d_toppart) { (void)hipFree(pl->d_toppart); pl->d_toppart = nullptr; }
+    if (pl->top_K > 0) GPV_HIP(hipMalloc((void **)&pl->d_toppart, sizeof(double) * 66 * (size_t)pl->top_K));
     pl->mean_head_levels = 0;
     static const bool no_head = getenv("GPV_NO_MEAN_HEAD") != nullptr;
     while (!no_head && (size_t)pl->mean_head_levels + 1 < pl->levptr2.size() &&

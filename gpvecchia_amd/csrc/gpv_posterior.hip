@@ -49,19 +49,14 @@ __device__ __forceinline__ int4 nt_load(const int4 *p)
 #endif
 constexpr int kRC = 16, kSub = 4, kTS = kRC + 1;      // columns per round, lanes per column, tile row stride (doubles)
 
-template <int WPC>
-__global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level_kernel(const PostArgs A, int first, int count)
+// One column of the factor.  c0, c1: its column record.
+// MODE 1 (the columns of the dense top block, gpv_posterior_top_kernel): no epilogue, the partial sums (64 rows, z2, s) go to
+// tpart; the first entries of the row list, up to c1.y, are the other top columns, whose R and t do not exist yet: their
+// B B^T terms and B a are taken here, their R R^T terms and R t are the top kernel's part.
+template <int WPC, int MODE = 0>
+__device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, const int4 c1, double *T, const int wib,
+                                            const int lane, double *tpart = nullptr)
 {
-    extern __shared__ double tile_all[];
-    const int lane = threadIdx.x & 63;
-    const int wib = threadIdx.x >> 6;
-    const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
-    if (WPC == 1 && w >= count) return;
-    double *T = tile_all + (size_t)wib * A.ld * kTS;
-    // the structure records are read once per evaluation: non-temporal, so that ~0.3 GB of them per pass do not push the
-    // set kernel's index stream and location records out of the Infinity Cache between evaluations
-    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
-    const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
     const int k = c0.x;
     const int cnt = c0.z;                            // latent entries of column k, ascending rows, self (= k) last
     const int qb = c0.w, qe = c1.x;                  // row list of k: columns ascending, first is k itself
@@ -91,7 +86,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
             if (sub == 0) z2 = __builtin_fma(Bk, head.x, z2);
             ne = rr.z >> 8;                    // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
             tb = rr.y;
-            if (ne > 0) {
+            if (ne > 0 && !(MODE == 1 && q < c1.y)) {
                 Rk = own.y;
                 if (sub == 0) s = __builtin_fma(Rk, head.y, s);
             }
@@ -118,7 +113,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
             }
 #pragma unroll
             for (int u = 0; u < EC; ++u)
-                if (pv[u] >= 0) T[pv[u] * kTS + col] = br[u].x * Bk - br[u].y * Rk;
+                if (pv[u] >= 0) T[pv[u] * kTS + col] = br[u].x * Bk - br[u].y * Rk;      // (MODE 1, top column: Rk = 0, R_.c = 0)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -160,6 +155,11 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
             s += part[v][65];
         }
     }
+    if constexpr (MODE == 1) {
+        tpart[lane] = acc;
+        if (lane == 0) { tpart[64] = z2; tpart[65] = s; }
+        return;
+    }
     if (lane < cnt) acc = __builtin_fma(bk_own, dk, acc);             // c == k term: B_ik d_k
     const double accd = __shfl(acc, cnt - 1, 64) + 1.0 / tau;
     const double rkk = sqrt(accd);
@@ -171,6 +171,23 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
         A.tvec[k] = t;
         A.logr[k] = log(rkk);
     }
+}
+
+template <int WPC, int MODE = 0>
+__global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level_kernel(const PostArgs A, int first, int count,
+                                                                                        double *tailpart, int tail_base)
+{
+    extern __shared__ double tile_all[];
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
+    if (WPC == 1 && w >= count) return;
+    double *T = tile_all + (size_t)wib * A.ld * kTS;
+    // the structure records are read once per evaluation: non-temporal, so that ~0.3 GB of them per pass do not push the
+    // set kernel's index stream and location records out of the Infinity Cache between evaluations
+    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
+    const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
+    post_column<WPC, MODE>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : tailpart + 66 * (size_t)(first + w - tail_base));
 }
 
 // C <- (B, 0) from the row-major Lentries, heads <- (a, 0): one thread per compact entry, coalesced writes
@@ -217,9 +234,164 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
     }
 }
 
+// ---- the dense top block ------------------------------------------------------------------------------------------
+// The first points of the ordering condition on (nearly) all of their predecessors and are conditioned on by thousands of
+// later points: as columns of the schedule they form a chain of ~35 single-column levels (n = 1e6, m = 30, maxmin), 5-8 us
+// each as launches of their own.  The plan therefore takes the columns k < K = min(n, 64) out of the schedule.  Their rows
+// lie inside the block (rows precede the column), so after every other column is final
+//   (1) gpv_posterior_level_kernel<16, 1> reduces, for all K columns at once, everything that does not involve the R and t
+//       of another top column (tpart: per column 64 row sums, B a, and the R t sum over the columns outside the block), and
+//   (2) this kernel finishes the block as a dense UL factorisation held in the registers of ONE wavefront: lane i owns row
+//       i, register c column c; for c = K-1 .. 0: R_cc = sqrt(S_cc), R_ic = S_ic / R_cc on the pattern (an entry off the
+//       pattern stays 0: the zero-fill rule of the level kernels), t_c = (z2_c - s_c) / R_cc, then S_ik -= R_ic R_kc for
+//       k < c (column c of R travels to all lanes as LDS broadcast reads) and s_i += R_ic t_c.
+// The other waves of the workgroup only help to load the block through LDS and to store the result.
+constexpr int kTop = 64;
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(v), l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <int C>
+struct TopStep {
+    static __device__ __forceinline__ void run(double (&S)[kTop], double *Rb, const unsigned long long m, const int lane,
+                                               const double z2, double &sv, double &tv, double &rd)
+    {
+        const double d = S[C];
+        const double rcc = sqrt(readlane_f64(d, C));
+        const bool on = (m >> C) & 1ull;
+        const double Rc = on ? ((lane == C) ? rcc : d / rcc) : 0.0;
+        S[C] = Rc;
+        // column c of R to every lane: through LDS (one wavefront: its LDS operations complete in order), read back as
+        // broadcasts; v_readlane would cost two SGPR round trips with their hazard stalls per element
+        Rb[lane] = Rc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double tc = (readlane_f64(z2, C) - readlane_f64(sv, C)) / rcc;
+        if (lane == C) { tv = tc; rd = rcc; }
+        sv = __builtin_fma(Rc, tc, sv);
+        const double nR = -Rc;
+#pragma unroll
+        for (int k = 0; k < C; ++k) S[k] = __builtin_fma(nR, Rb[k], S[k]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if constexpr (C > 0) TopStep<C - 1>::run(S, Rb, m, lane, z2, sv, tv, rd);
+    }
+};
+constexpr int kTopWaves = 4, kTopJ = kTop / kTopWaves;   // 4 waves = one per SIMD: the factorising wave may use the whole VGPR file
+__global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const PostArgs A, const double *tpart, const int K)
+{
+    __shared__ double Sl[kTop][kTop + 1];            // the block by (row, column)
+    __shared__ unsigned char Pl[kTop][kTop];         // 1: (row, column) on the pattern
+    __shared__ double zl[kTop], sl[kTop], tl[kTop], rl[kTop];
+    __shared__ __attribute__((aligned(16))) double Rb[kTop];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < kTop; r += kTopWaves) {
+        Sl[r][lane] = (r == lane && r >= K) ? 1.0 : 0.0;           // columns past K: identity (R = 1, t = 0)
+        Pl[r][lane] = (r == lane && r >= K) ? 1 : 0;
+    }
+    if (wave == 0) { zl[lane] = 0.0; sl[lane] = 0.0; }
+    __syncthreads();
+    // wave w loads the columns w, w + 4, ..: lane = entry of the column.  Loads first, all of them in flight together
+    int cpj[kTopJ], cntj[kTopJ], rowi[kTopJ];
+#pragma unroll
+    for (int j = 0; j < kTopJ; ++j) {
+        const int k = wave + kTopWaves * j;
+        cpj[j] = (k < K) ? A.colptr[k] : 0;
+        cntj[j] = (k < K) ? A.colptr[k + 1] - cpj[j] : 0;
+    }
+    double vb[kTopJ], vd[kTopJ], vp[kTopJ], vt[kTopJ], vz[kTopJ], vpz[kTopJ], vps[kTopJ];
+#pragma unroll
+    for (int j = 0; j < kTopJ; ++j) {
+        const int k = wave + kTopWaves * j;
+        const bool own = lane < cntj[j];
+        const double2 *Ck = A.C + (int64_t)cpj[j] + k;
+        rowi[j] = own ? A.crow[cpj[j] + lane] : -1;
+        vb[j] = own ? Ck[1 + lane].x : 0.0;
+        vd[j] = own ? Ck[cntj[j]].x : 0.0;
+        vp[j] = own ? tpart[66 * (size_t)k + lane] : 0.0;
+        vt[j] = own ? ((A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar) : 1.0;
+        const bool last = own && lane == cntj[j] - 1;
+        vz[j] = last ? A.z[k] : 0.0;
+        vpz[j] = last ? tpart[66 * (size_t)k + 64] : 0.0;
+        vps[j] = last ? tpart[66 * (size_t)k + 65] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < kTopJ; ++j) {
+        const int k = wave + kTopWaves * j;
+        if (rowi[j] >= 0) {
+            double v = __builtin_fma(vb[j], vd[j], vp[j]);                 // c == k term: B_ik d_k
+            if (lane == cntj[j] - 1) {
+                v += 1.0 / vt[j];
+                zl[k] = vpz[j] - vz[j] / vt[j];
+                sl[k] = vps[j];
+            }
+            Sl[rowi[j]][k] = v;
+            Pl[rowi[j]][k] = 1;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        double S[kTop];
+        unsigned long long m = 0ull;
+#pragma unroll
+        for (int c = 0; c < kTop; ++c) {
+            S[c] = Sl[lane][c];
+            m |= (unsigned long long)Pl[lane][c] << c;
+        }
+        const double z2 = zl[lane];
+        double sv = sl[lane], tv = 0.0, rd = 1.0;
+        TopStep<kTop - 1>::run(S, Rb, m, lane, z2, sv, tv, rd);
+#pragma unroll
+        for (int c = 0; c < kTop; ++c) Sl[lane][c] = S[c];
+        tl[lane] = tv;
+        rl[lane] = rd;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kTopJ; ++j) {
+        const int k = wave + kTopWaves * j;
+        if (k < K) {
+            double2 *Ck = A.C + (int64_t)cpj[j] + k;
+            if (rowi[j] >= 0) Ck[1 + lane].y = Sl[rowi[j]][k];
+            if (lane == 0) {
+                const double t = tl[k];
+                Ck[0].y = t;
+                A.tvec[k] = t;
+                A.logr[k] = log(rl[k]);
+            }
+        }
+    }
+}
+
+// the top block: positions [first, first + K) of the column records hold the columns 0 .. K-1; tpart: [K][66] scratch
+hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, hipStream_t s)
+{
+    if (K <= 0) return hipSuccess;
+    if (K > kTop) return hipErrorInvalidValue;
+    const size_t smem = (size_t)16 * a.ld * kTS * sizeof(double);
+    if (smem > 64 * 1024) {                                   // > 64 KiB of dynamic LDS needs the opt-in, once per device
+        static std::atomic<unsigned long long> done{0ull};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+            done.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
+    hipLaunchKernelGGL(gpv_posterior_top_kernel, dim3(1), dim3(64 * kTopWaves), 0, s, a, (const double *)tpart, K);
+    return hipGetLastError();
+}
+
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
+    double *const np = nullptr;
     if (leaves) {
         hipLaunchKernelGGL(gpv_posterior_leaf_kernel, dim3((count + 15) / 16), dim3(256), 0, s, a, first, count);
         return hipGetLastError();
@@ -232,22 +404,22 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool 
             (void)hipGetDevice(&dev);
             const unsigned long long bit = 1ull << (dev & 63);
             if (!(done.load(std::memory_order_relaxed) & bit)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
-        hipLaunchKernelGGL(gpv_posterior_level_kernel<16>, dim3(count), dim3(1024), smem, s, a, first, count);
+        hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
         return hipGetLastError();
     }
     if (count <= GPV_POST_WIDE) {                             // narrow level: the chip is not full anyway, 8 waves per column
         const size_t smem = (size_t)8 * a.ld * kTS * sizeof(double);
-        hipLaunchKernelGGL(gpv_posterior_level_kernel<8>, dim3(count), dim3(512), smem, s, a, first, count);
+        hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
         return hipGetLastError();
     }
     const int wpb = 4;
     const size_t smem = (size_t)wpb * a.ld * kTS * sizeof(double);
-    hipLaunchKernelGGL(gpv_posterior_level_kernel<1>, dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count);
+    hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0);
     return hipGetLastError();
 }
 

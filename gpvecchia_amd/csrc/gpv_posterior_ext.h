@@ -1,7 +1,6 @@
-// gpv_posterior_ext.h — single-workgroup kernels for the NARROW levels of the posterior pass (gpv_posterior.hip).
-// A level with a handful of columns costs 5-7 us as a launch of its own (dispatch, kernel-argument load, cold dependent
-// loads, end-of-kernel cache actions); consecutive narrow levels therefore run inside ONE workgroup, separated by
-// workgroup barriers instead of kernel boundaries.
+// gpv_posterior_ext.h — the kernels that take the NARROW ends of the posterior pass's two schedules out of the per-level
+// launches (gpv_posterior.hip).  A level with a handful of columns costs 5-8 us as a launch of its own (dispatch, cold
+// dependent loads, end-of-kernel cache actions, and the trip through memory between consecutive levels).
 #pragma once
 #include "gpv_internal.h"
 
@@ -10,4 +9,9 @@ namespace gpv {
 // most kMeanHeadMax columns wide; levptr2: device copy of the level offsets into order2
 constexpr int kMeanHeadMax = 32;
 hipError_t launch_mean_head(const PostArgs &a, const int32_t *order2, double *u, const int32_t *levptr2, int nlev, hipStream_t s);
+// Factor pass: the dense top block, columns 0 .. K-1 (K <= kTopMax) of the ordering, which the plan keeps out of the level
+// schedule (gpv_posterior.hip, gpv_posterior_top_kernel).  Their column records sit at positions [first, first + K) of
+// colrec, ascending, with colrec[..][1].y = the end of the row-list entries that are top columns themselves; tpart: [K][66].
+constexpr int kTopMax = 64;
+hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, hipStream_t s);
 }  // namespace gpv

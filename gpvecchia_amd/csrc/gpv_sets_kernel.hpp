@@ -6,10 +6,9 @@
 // R^T R = S and x = R^{-1} e_last, stored left-aligned in Lentries[k,].
 //
 // How (not a translation of the reference):
-//   * one wavefront handles SPW = floor(64/LPS) conditioning sets at once; a set is spread
-//     over LPS lanes and lane (sub, i) owns the rows i, i+LPS, .. (RPL rows per lane: 2 for
-//     24 <= P <= 41, 1 otherwise) of the symmetric block in 2*RPL*P VGPRs.  Two rows per lane halve
-//     the LDS broadcast volume per FMA and the per-pivot overhead per set;
+//   * one wavefront handles SPW = floor(64/LPS) conditioning sets at once; a set is spread over LPS lanes and lane
+//     (sub, i) owns the rows i, i+LPS, .. of the symmetric block in 2*RPL*P VGPRs.  Geometries (Geo<P>): one 16-lane
+//     DPP row per set for 12 <= P <= 48, a pair of DPP rows for 49 <= P <= 64, P (+1) lanes with one row each below;
 //   * neighbour indices / cond flags are read as one contiguous segment per set,
 //     coordinates and datum gathered as one 32-byte record per neighbour and staged in LDS;
 //   * the P(P-1)/2 distinct covariances are evaluated once each with a circulant
@@ -21,16 +20,16 @@
 //     b = S11^{-1} s_l and v = s_ll - s_l^T b (Schur complement) one has
 //     x = [-b ; 1] / sqrt(v).  b and v come from a Gauss-Jordan sweep over the
 //     first P-1 pivots in which EVERY lane keeps working (rows above the pivot
-//     are reduced too), the pivot row is exchanged through a 2-slot LDS buffer
-//     with broadcast reads that are software-pipelined in chunks against the FMAs,
-//     and the pivots are exactly the Schur complements d_j^2 whose positivity
-//     decides "Cholesky failed" in the reference (:60-66);
+//     are reduced too).  The pivot-row element each FMA needs sits, by symmetry, in a register of another lane of
+//     the set: the DPP geometries read it there with v_fmac_f64_dpp ... row_newbcast (no LDS, no wait in the sweep),
+//     the small geometries exchange the pivot row through a 2-slot LDS buffer with broadcast reads.  The pivots are
+//     exactly the Schur complements d_j^2 whose positivity decides "Cholesky failed" in the reference (:60-66);
 //   * a spare row slot (P odd, or a spare lane) carries the DATA as one more row of the
 //     sweep: after the last pivot it holds -mu_k = -sum_j b_j z_j, the conditional mean needed
 //     by the likelihood, at zero extra instructions (no cross-lane reduction);
 //   * optional fused epilogue: the log-likelihood partial sums of
-//     R/vecchia_likelihood.R:74-76 (and the closed form for cond.yz='z'), so a
-//     likelihood evaluation never writes the 248 MB factor to HBM.
+//     R/vecchia_likelihood.R:74-76 (and the closed form for cond.yz='z') accumulate in registers over the whole task
+//     loop (no log() per set), so a likelihood evaluation never writes the 248 MB factor to HBM.
 //   No MFMA (blocks are tiny), no global atomics, deterministic reductions.
 #pragma once
 #include "gpv_internal.h"

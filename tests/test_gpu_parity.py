@@ -6,6 +6,8 @@ and log-likelihood within 1e-8 relative.  U entries are compared NORMWISE PER RO
 (max|dM| / max|M| <= 1e-8): SURVEY.md §8d shows two correct fp64 implementations
 differ elementwise by cond(S)*eps, so an elementwise bound is only asserted on the
 well-conditioned cases (where 1e-10 holds)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -650,6 +652,49 @@ def test_sgv_posterior_pass_wide_levels():
     assert abs(ll - ll_host) <= 1e-9 * abs(ll_host)
     # bitwise reproducible
     assert G.vecchia_likelihood(z, va, cp, tau) == ll and np.array_equal(plan.sums(), s1)
+
+
+_TOP_SNIPPET = r"""
+import json, sys
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process: conftest.py)
+import gpvecchia_amd as G
+out = {}
+for n, m in [(40, 10), (63, 20), (64, 20), (65, 20), (700, 30), (5000, 25)]:
+    rng = np.random.default_rng(n)
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    tau = 0.1 + 0.2 * rng.random(n)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
+    ll = G.vecchia_likelihood(z, va, [1.3, 0.2, 1.5], tau)
+    sums = va[("_plan", 0)].sums().tolist()
+    mu = G.vecchia_prediction(z, va, [1.3, 0.2, 1.5], tau)["mu_obs"].tolist()
+    out[str(n)] = dict(ll=ll, sums=sums, mu=mu, levels=va[("_plan", 0)].posterior_levels())
+print("RESULT" + json.dumps(out))
+"""
+
+
+def test_dense_top_block_of_posterior_pass_matches_level_schedule():
+    # the first min(n, 64) columns of the ordering are factorised by gpv_posterior_top_kernel instead of ~35 single-column
+    # levels; GPV_POST_TOP=0 schedules every column.  Same factor (different summation order): the log-likelihood, the
+    # log-determinant / quadratic form of W and the posterior mean agree to rounding, for n below, at and above the block size
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for top in ("0", "1"):
+        env = dict(os.environ, GPV_POST_TOP=top, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _TOP_SNIPPET], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[top] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+    for key, a in res["0"].items():
+        b = res["1"][key]
+        assert b["levels"] < a["levels"] or int(key) <= 64
+        assert abs(a["ll"] - b["ll"]) <= 1e-11 * abs(a["ll"]), key
+        np.testing.assert_allclose(b["sums"][2:4], a["sums"][2:4], rtol=1e-11, err_msg=key)
+        np.testing.assert_allclose(b["mu"], a["mu"], rtol=0, atol=1e-10 * np.abs(a["mu"]).max(), err_msg=key)
+    assert res["1"]["40"]["levels"] == 0 and res["1"]["64"]["levels"] == 0 and res["1"]["65"]["levels"] == 1
 
 
 @pytest.mark.parametrize("cond", ["SGV", "z"])
