@@ -242,7 +242,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
 //   (1) gpv_posterior_level_kernel<16, 1> reduces, for all K columns at once, everything that does not involve the R and t
 //       of another top column (tpart: per column 64 row sums, B a, and the R t sum over the columns outside the block), and
 //   (2) this kernel finishes the block as a dense UL factorisation held in the registers of ONE wavefront: lane i owns row
-//       i, register c column c; for c = K-1 .. 0: R_cc = sqrt(S_cc), R_ic = S_ic / R_cc on the pattern (an entry off the
+//       i, register c column c; for c = 63 .. 0: R_cc = sqrt(S_cc), R_ic = S_ic / R_cc on the pattern (an entry off the
 //       pattern stays 0: the zero-fill rule of the level kernels), t_c = (z2_c - s_c) / R_cc, then S_ik -= R_ic R_kc for
 //       k < c (column c of R travels to all lanes as LDS broadcast reads) and s_i += R_ic t_c.
 // The other waves of the workgroup only help to load the block through LDS and to store the result.
@@ -253,31 +253,59 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double((int)hi, (int)lo);
 }
+// pivot of the top block: r = sqrt(x) and 1/r from one v_rsq_f64 seed (Goldschmidt), x > 0; x <= 0 or NaN gives NaN like sqrt()
+__device__ __forceinline__ void top_pivot(const double x, double &r, double &rinv)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    r = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    const double w = h + h;
+    rinv = __builtin_fma(w, __builtin_fma(-r, w, 1.0), w);
+}
+// a / r given rinv ~ 1/r: product plus one residual correction
+__device__ __forceinline__ double top_div(const double a, const double r, const double rinv)
+{
+    const double q = a * rinv;
+    return __builtin_fma(__builtin_fma(-q, r, a), rinv, q);
+}
+// Step C of the factorisation.  On entry column C of R is final: Rc in this lane's register and, for all rows, in Rb.  The
+// pivot column of the NEXT step is updated first, then the other C-1 columns.  (Interleaving the next pivot's serial chain
+// with those updates by hand, scheduling barriers and all, measured the same 48 us for the block: not kept.)
 template <int C>
 struct TopStep {
     static __device__ __forceinline__ void run(double (&S)[kTop], double *Rb, const unsigned long long m, const int lane,
-                                               const double z2, double &sv, double &tv, double &rd)
+                                               const double z2, double &sv, double &tv, double &rd, const double Rc,
+                                               const double rcc, const double rinv)
     {
-        const double d = S[C];
-        const double rcc = sqrt(readlane_f64(d, C));
-        const bool on = (m >> C) & 1ull;
-        const double Rc = on ? ((lane == C) ? rcc : d / rcc) : 0.0;
-        S[C] = Rc;
-        // column c of R to every lane: through LDS (one wavefront: its LDS operations complete in order), read back as
-        // broadcasts; v_readlane would cost two SGPR round trips with their hazard stalls per element
-        Rb[lane] = Rc;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double tc = (readlane_f64(z2, C) - readlane_f64(sv, C)) / rcc;
+        double rb[C > 0 ? C : 1];
+#pragma unroll
+        for (int k = 0; k < C; ++k) rb[k] = Rb[k];
+        const double tc = top_div(readlane_f64(z2, C) - readlane_f64(sv, C), rcc, rinv);
         if (lane == C) { tv = tc; rd = rcc; }
         sv = __builtin_fma(Rc, tc, sv);
-        const double nR = -Rc;
+        if constexpr (C > 0) {
+            const double nR = -Rc;
+            const double d = __builtin_fma(nR, rb[C - 1], S[C - 1]);
+            double rn, rninv;
+            top_pivot(readlane_f64(d, C - 1), rn, rninv);
+            const bool on = (m >> (C - 1)) & 1ull;
+            const double Rn = on ? ((lane == C - 1) ? rn : top_div(d, rn, rninv)) : 0.0;
+            S[C - 1] = Rn;
 #pragma unroll
-        for (int k = 0; k < C; ++k) S[k] = __builtin_fma(nR, Rb[k], S[k]);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if constexpr (C > 0) TopStep<C - 1>::run(S, Rb, m, lane, z2, sv, tv, rd);
+            for (int k = 0; k < C - 1; ++k) S[k] = __builtin_fma(nR, rb[k], S[k]);
+            // column C-1 of R to every lane: through LDS (one wavefront: its LDS operations complete in order), read back
+            // as broadcasts; v_readlane would cost two SGPR round trips with their hazard stalls per element
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            Rb[lane] = Rn;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            TopStep<C - 1>::run(S, Rb, m, lane, z2, sv, tv, rd, Rn, rn, rninv);
+        }
     }
 };
 constexpr int kTopWaves = 4, kTopJ = kTop / kTopWaves;   // 4 waves = one per SIMD: the factorising wave may use the whole VGPR file
@@ -343,7 +371,18 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
         }
         const double z2 = zl[lane];
         double sv = sl[lane], tv = 0.0, rd = 1.0;
-        TopStep<kTop - 1>::run(S, Rb, m, lane, z2, sv, tv, rd);
+        {
+            const double d = S[kTop - 1];
+            double r0, r0inv;
+            top_pivot(readlane_f64(d, kTop - 1), r0, r0inv);
+            const double R0 = ((m >> (kTop - 1)) & 1ull) ? ((lane == kTop - 1) ? r0 : top_div(d, r0, r0inv)) : 0.0;
+            S[kTop - 1] = R0;
+            Rb[lane] = R0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            TopStep<kTop - 1>::run(S, Rb, m, lane, z2, sv, tv, rd, R0, r0, r0inv);
+        }
 #pragma unroll
         for (int c = 0; c < kTop; ++c) Sl[lane][c] = S[c];
         tl[lane] = tv;
