@@ -858,7 +858,7 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
         if (total >= ((int64_t)1 << 31)) return GPV_ERR_BAD_ARG;              // 32-bit offsets into the match records
     }
     for (size_t q = 0; q < nnz; ++q) tptr[q + 1] += tptr[q];
-    std::vector<uint8_t> tp((size_t)tptr[nnz]);
+    std::vector<uint8_t> tp((size_t)tptr[nnz] + 16);          // padded: the kernels read one (masked) byte at a record's start even when it is empty
     {
         const int32_t *cp_ = colptr.data(), *cr_ = crow.data(), *qo_ = qof.data(), *tq_ = tptr.data();
         uint8_t *tp_ = tp.data();

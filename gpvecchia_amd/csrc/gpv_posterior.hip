@@ -75,17 +75,29 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     double acc = 0.0, z2 = 0.0, s = 0.0;
     for (int base = qb + kRC * ((WPC == 1) ? 0 : wib); base < qe; base += kRC * WPC) {
         const int q = base + col;
-        int tb = 0, ne = 0;
-        const double2 *Cc = A.C;
+        // One trip for everything the round reads behind the row-list record: the (a_c, t_c) head, the (B_kc, R_kc) pair, and
+        // the first EC match bytes and (B, R) pairs of each lane.  No branches around the loads (an idle lane reads the
+        // round's first record, an entry past the end reads entry 0, both masked afterwards): with per-lane branches the
+        // compiler serialises them into two dependent trips.
+        constexpr int EC = GPV_POST_EC;
+        const bool act = q < qe;
+        const int4 rr = nt_load(&A.rowrec[act ? q : base]);
+        const double2 *Cc = A.C + rr.x;
+        const int ne = act ? (rr.z >> 8) : 0;   // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
+        const int tb = rr.y;
+        const double2 head = Cc[0], own = Cc[1 + (rr.z & 255)];         // (a_c, t_c), (B_kc, R_kc)
+        int pv[EC];
+        double2 br[EC];
+#pragma unroll
+        for (int u = 0; u < EC; ++u) {
+            const int e = sub + u * kSub;
+            pv[u] = (int)__builtin_nontemporal_load(&A.tp[tb + (e < ne ? e : 0)]);
+            br[u] = Cc[1 + (e < ne ? e : 0)];
+        }
         double Bk = 0.0, Rk = 0.0;
-        if (q < qe) {
-            const int4 rr = nt_load(&A.rowrec[q]);
-            Cc = A.C + rr.x;
-            const double2 head = Cc[0], own = Cc[1 + (rr.z & 255)];     // (a_c, t_c), (B_kc, R_kc)
+        if (act) {
             Bk = own.x;
             if (sub == 0) z2 = __builtin_fma(Bk, head.x, z2);
-            ne = rr.z >> 8;                    // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
-            tb = rr.y;
             if (ne > 0 && !(MODE == 1 && q < c1.y)) {
                 Rk = own.y;
                 if (sub == 0) s = __builtin_fma(Rk, head.y, s);
@@ -96,24 +108,20 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // entries sub, sub+4, ... of the column: one match byte, one 16-byte (B, R) gather and one LDS store each
-        constexpr int EC = GPV_POST_EC;
-        for (int e0 = sub; __builtin_amdgcn_ballot_w64(e0 < ne) != 0; e0 += EC * kSub) {
-            int pv[EC];
+        // (0xFF: the row is not in column k (never under SGV) => zero fill; MODE 1, top column: Rk = 0, R_.c = 0)
+#pragma unroll
+        for (int u = 0; u < EC; ++u)
+            if (sub + u * kSub < ne && pv[u] != 0xFF) T[pv[u] * kTS + col] = br[u].x * Bk - br[u].y * Rk;
+        for (int e0 = sub + EC * kSub; __builtin_amdgcn_ballot_w64(e0 < ne) != 0; e0 += EC * kSub) {   // longer columns
 #pragma unroll
             for (int u = 0; u < EC; ++u) {
                 const int e = e0 + u * kSub;
-                const int v = (e < ne) ? (int)__builtin_nontemporal_load(&A.tp[tb + e]) : 0xFF;
-                pv[u] = (v == 0xFF) ? -1 : v;            // 0xFF: the row is not in column k (never under SGV) => zero fill
-            }
-            double2 br[EC];                              // address known from the row-list record: issued with the match bytes
-#pragma unroll
-            for (int u = 0; u < EC; ++u) {
-                br[u] = make_double2(0.0, 0.0);
-                if (e0 + u * kSub < ne) br[u] = Cc[1 + e0 + u * kSub];
+                pv[u] = (int)__builtin_nontemporal_load(&A.tp[tb + (e < ne ? e : 0)]);
+                br[u] = Cc[1 + (e < ne ? e : 0)];
             }
 #pragma unroll
             for (int u = 0; u < EC; ++u)
-                if (pv[u] >= 0) T[pv[u] * kTS + col] = br[u].x * Bk - br[u].y * Rk;      // (MODE 1, top column: Rk = 0, R_.c = 0)
+                if (e0 + u * kSub < ne && pv[u] != 0xFF) T[pv[u] * kTS + col] = br[u].x * Bk - br[u].y * Rk;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
