@@ -240,7 +240,7 @@ __device__ __forceinline__ double rcp_pivot_bounded(double x)
     return r;
 }
 
-// sqrt(x), x > 0 normal: v_rsq_f64 seed + one coupled Goldschmidt step + one residual step
+// sqrt(x), x > 0 normal: v_rsq_f64 seed + one Goldschmidt step on g + one residual step
 // (error ~1 ulp; x == 0 gives NaN, callers select the dist==0 value separately).
 __device__ __forceinline__ double sqrt_pos(double x)
 {
@@ -249,7 +249,7 @@ __device__ __forceinline__ double sqrt_pos(double x)
     double h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
     g = __builtin_fma(g, r, g);
-    h = __builtin_fma(h, r, h);
+    // (h keeps the seed's ~2^-27 relative error: it only scales the residual d, itself ~2^-53 of g)
     const double d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
@@ -297,6 +297,61 @@ __device__ __forceinline__ double exp_neg(double t)
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
     return __builtin_ldexp(p, (int)kd);
+}
+
+// LDS through absolute 32-bit byte addresses (address arithmetic in one VGPR, the constant part in the DS offset field)
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+typedef __attribute__((address_space(3))) double lds_wdouble;
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char *)p;
+}
+__device__ __forceinline__ lds_cdouble *lds_ptr(unsigned a) { return (lds_cdouble *)(uintptr_t)a; }
+__device__ __forceinline__ lds_wdouble *lds_wptr(unsigned a) { return (lds_wdouble *)(uintptr_t)a; }
+
+// scale * exp(-t) for the closed-form Matern families, two instructions shorter per value than scale * exp_neg(t):
+//   * the Horner coefficients are multiplied by scale (= sigma^2) once per wavefront and kept in SGPRs, so the value
+//     leaves the polynomial already scaled;
+//   * k = round(-t log2 e) is taken from the low mantissa bits of -t log2 e + 1.5 * 2^52 and added straight into the
+//     exponent field of the result (no v_cvt_i32_f64, no v_ldexp_f64).  t is clamped so that the result stays a normal
+//     number (tmax: 700, less what a scale below 1 takes from the exponent range); past the clamp the value is
+//     scale * e^-tmax < 1e-300 instead of 0.
+struct ExpScaled {
+    double c[12];                                   // scale * (c11 .. c2), then scale, scale
+    double tmax;
+};
+__device__ __forceinline__ double sgpr_f64(double x)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ ExpScaled exp_scaled_setup(const double scale)
+{
+    constexpr double k[10] = {0x1.af631d0059becp-26, 0x1.28b4057f44145p-22, 0x1.71ddf5749d126p-19, 0x1.a01991ac8730ap-16,
+                              0x1.a01a01b14378fp-13, 0x1.6c16c187fbe02p-10, 0x1.111111110f225p-7,  0x1.555555554f0cfp-5,
+                              0x1.555555555555ap-3,  0x1.0000000000011p-1};
+    ExpScaled E;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) E.c[i] = sgpr_f64(k[i] * scale);
+    E.c[10] = E.c[11] = sgpr_f64(scale);
+    const int es = __builtin_amdgcn_frexp_exp(scale);                       // scale = m 2^es, m in [0.5, 1)
+    const double room = (double)(1010 + (es < 0 ? es : 0)) * 0.6931471805599453;
+    E.tmax = sgpr_f64(__builtin_fmin(__builtin_fmax(room, 0.0), 700.0));
+    return E;
+}
+__device__ __forceinline__ double exp_neg_scaled(double t, const ExpScaled &E)
+{
+    t = __builtin_fmin(t, E.tmax);
+    const double kk = __builtin_fma(t, -1.4426950408889634, 0x1.8p52);
+    const double kd = kk - 0x1.8p52;
+    double r = __builtin_fma(kd, -6.93147180369123816490e-01, -t);
+    r = __builtin_fma(kd, -1.90821492927058770002e-10, r);
+    double p = fma_vvs(E.c[0], r, E.c[1]);
+#pragma unroll
+    for (int i = 2; i < 12; ++i) p = fma_vvs(p, r, E.c[i]);
+    const int hi = __double2hiint(p) + (__double2loint(kk) << 20);
+    return __hiloint2double(hi, __double2loint(p));
 }
 
 // Running sum of logarithms without a log per term: log(x_1 ... x_T) = log(prod) + esum ln 2 with the product kept in
@@ -430,7 +485,7 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
 template <int COV, bool TAB = false, int MTW = 0>
 __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
-                                             const SetArgs &A, const double *mt_lds = nullptr)
+                                             const SetArgs &A, const ExpScaled &E, const double *mt_lds = nullptr)
 {
     if constexpr (COV == COV_MATERN_GEN && TAB) {
         const double v = matern_table_only<MTW>(A.mt, A.mt_base, A.mt_nseg, A.mt_win, mt_lds,
@@ -442,13 +497,13 @@ __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, 
     const double dist = sqrt_pos(r2);
     if constexpr (COV == COV_MATERN15) {
         const double t = dist * cA;
-        const double e = exp_neg(t);
-        return sA * __builtin_fma(t, e, e);
+        const double e = exp_neg_scaled(t, E);       // sigma^2 exp(-t)
+        return __builtin_fma(t, e, e);
     } else if constexpr (COV == COV_MATERN05) {
-        return sA * exp_neg(dist * cA);
+        return exp_neg_scaled(dist * cA, E);
     } else if constexpr (COV == COV_MATERN25) {
         const double t = dist * cA;
-        return sA * exp_neg(t) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
+        return exp_neg_scaled(t, E) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
     } else {
         return __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));
     }
@@ -485,6 +540,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     Lds &L = lds_all[wv];
 
     const double sig0 = A.sig0, sA = A.sA, cA = A.cA, sB = A.sB, cB = A.cB;
+    const ExpScaled expS = exp_scaled_setup(sA);       // closed-form Matern families: sigma^2 exp(-t) (cov_closed)
     const unsigned long long setmask = (LPS == 64) ? ~0ull : (((1ull << LPS) - 1ull) << (sub * LPS));
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
@@ -510,6 +566,40 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     const int xcd = (nx == 8) ? (int)(blockIdx.x & 7) : 0, jb = (nx == 8) ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int nbx = (nx == 8) ? (int)((gridDim.x - xcd + 7) >> 3) : (int)gridDim.x;     // workgroups sharing this residue
     const int64_t task_lo = ntasks * xcd / nx, task_hi = ntasks * (xcd + 1) / nx;
+    // neighbour indices and cond flags are requested one task ahead: a task then starts with its (dependent) record gathers
+    // instead of with two trips in a row, which two wavefronts per SIMD do not always hide
+    int pidx[RPL], pcnd[RPL];
+    auto load_ic = [&](const int64_t t) __attribute__((always_inline)) {
+        const int64_t kk = t * SPW + sub;
+        const bool on = lane_on && t < task_hi && kk < A.rows;
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {                      // no branches: an idle slot reads entry 0 and is masked
+            const int r = i_const + q * LPS;
+            const bool ld = on && r < P;
+            const int64_t at = ld ? kk * P + r : 0;
+            const int vi = A.nn[at];
+            const int vc = A.cond[at];
+            pidx[q] = ld ? vi : -1;
+            pcnd[q] = ld ? vc : 1;
+        }
+    };
+    load_ic(task_lo + (int64_t)jb * W + wv);
+    // DPP geometries, location records: the records of the next task are requested from the middle of the sweep, when half
+    // of the block's registers are free again and nothing else is in flight
+    constexpr bool PFREC = G::DPP && D != 0 && COV != COV_DENSE;
+    double2 pr0[RPL], pr1[RPL];
+    double pnug[RPL];
+    auto load_rec = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {                      // no branches: a missing neighbour reads record 0 and is masked
+            const int at = pidx[q] >= 0 ? pidx[q] : 0;
+            const double2 *rp = reinterpret_cast<const double2 *>(A.rec + (int64_t)at * 4);
+            pr0[q] = rp[0];
+            pr1[q] = rp[1];
+            pnug[q] = (A.nuggets != nullptr) ? A.nuggets[at] : A.nug_scalar;
+        }
+    };
+    if constexpr (PFREC) load_rec();
     for (int64_t task = task_lo + (int64_t)jb * W + wv; task < task_hi; task += (int64_t)nbx * W) {
         const int64_t k = task * SPW + sub;
         const bool set_on = lane_on && (k < A.rows);
@@ -528,12 +618,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         for (int q = 0; q < RPL; ++q) {
             row[q] = i + q * LPS;
             wslot[q] = lane_on ? row[q] : COLS - 1;          // idle lanes write to the dump slot: no branches in the sweep
-            idx[q] = -1;
-            cnd[q] = 1;
-            if (set_on && row[q] < P) {
-                idx[q] = A.nn[k * P + row[q]];
-                cnd[q] = A.cond[k * P + row[q]];
-            }
+            idx[q] = pidx[q];
+            cnd[q] = pcnd[q];
             valid[q] = idx[q] >= 0;
             poison[q] = false;                                // NaN coordinate => NaN block => "Cholesky failed"
             nugraw[q] = 0.0;
@@ -547,6 +633,11 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         L.xy[sub][row[q]][t] = c;
                     }
                     if (A.z != nullptr) zi[q] = A.z[idx[q]];
+                } else if constexpr (PFREC) {
+                    xi[q][0] = pr0[q].x;
+                    if constexpr (D >= 2) xi[q][1] = pr0[q].y;
+                    if constexpr (D >= 3) xi[q][2] = pr1[q].x;
+                    zi[q] = pr1[q].y;
                 } else {
                     // one 32-byte record per neighbour: coordinates and the datum travel together
                     const double2 *rp = reinterpret_cast<const double2 *>(A.rec + (int64_t)idx[q] * 4);
@@ -556,7 +647,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     if constexpr (D >= 3) xi[q][2] = r1.x;
                     zi[q] = r1.y;
                 }
-                nugraw[q] = (A.nuggets != nullptr) ? A.nuggets[idx[q]] : A.nug_scalar;
+                if constexpr (PFREC && D != 0) nugraw[q] = pnug[q];
+                else nugraw[q] = (A.nuggets != nullptr) ? A.nuggets[idx[q]] : A.nug_scalar;
             } else {
                 if constexpr (D != 0) {
 #pragma unroll
@@ -586,6 +678,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         }
         const int nmiss = P - nvalid;
         wave_sync();
+        load_ic(task + (int64_t)nbx * W);                     // the next task's indices travel during this task
 
         // ---- covariance: every unordered pair once, circulant pairing ------------------
         constexpr int H = P / 2;
@@ -647,13 +740,13 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             constexpr bool MASKED = decltype(masked_tag)::value;
             constexpr bool TAB = decltype(tab_tag)::value;           // general nu: table-only evaluation (no per-pair range test)
             constexpr int DS = Lds::DS, DD = (D == 0) ? 1 : D;
-            // 32-bit byte offsets inside the set's LDS slices (24-bit multiplies: one v_mad_u32_u24 per address)
-            const char *xyb = reinterpret_cast<const char *>(&L.xy[sub][0][0]);
-            char *trb = reinterpret_cast<char *>(&L.tri[sub][0]);
+            // absolute 32-bit LDS byte addresses, the slices' bases folded into the per-lane terms: per pair one select for the
+            // partner's coordinates, one add and one select for the triangle slot, the round's constants in the DS offset field
+            const unsigned xy0 = lds_addr(&L.xy[sub][0][0]), tr0 = lds_addr(&L.tri[sub][0]);
             int rq[RPL];
             bool vq[RPL];
             double xq[RPL][DD];
-            unsigned xoA[RPL], xoB[RPL], rq8[RPL], rt8[RPL], rtB8[RPL];
+            unsigned xoA[RPL], xoB[RPL], rq8[RPL], trA[RPL], trB[RPL];
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 const bool own = lane_on && row[q] < P;
@@ -661,14 +754,17 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #pragma unroll
                 for (int t = 0; t < D; ++t) xq[q][t] = own ? xi[q][t] : L.xy[sub][0][t];
                 vq[q] = own ? valid[q] : (bool)((vmask[0] >> (sub * LPS)) & 1ull);
-                xoA[q] = __umul24(rq[q], DS * 8);
-                xoB[q] = xoA[q] - P * DS * 8;
+                xoA[q] = xy0 + __umul24(rq[q], DS * 8);
+                xoB[q] = xoA[q] - P * DS * 8;                           // (used by the lanes with row + s >= P only)
                 rq8[q] = rq[q] * 8;
-                rt8[q] = __umul24(rq[q], rq[q] + 1) * 4;
-                rtB8[q] = rt8[q] + rq8[q];
+                // slot of the pair (r, r+s), minus 8 s: r+s < P: tri + 8 (rt + r (s+1) + s(s+1)/2 - s), kept incrementally;
+                // wrapped (j = r+s-P < r): tri + 8 (rt + j - s) = tri + 8 (rt + r - P), constant
+                const unsigned rt8 = tr0 + __umul24(rq[q], rq[q] + 1) * 4;
+                trA[q] = rt8 + 2 * rq8[q];                              // s = 1
+                trB[q] = rt8 + rq8[q] - 8 * P;
             }
             auto fetch = [&](int q, int s, double (&dst)[DD]) {
-                const double *xj = reinterpret_cast<const double *>(xyb + ((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * DS * 8);
+                const lds_cdouble *xj = lds_ptr(((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * DS * 8);
 #pragma unroll
                 for (int t = 0; t < D; ++t) dst[t] = xj[t];
             };
@@ -696,7 +792,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV, TAB, MTW>(r2, sig0, sA, cA, sB, cB, A, mt_lds);
+                    v[q] = cov_closed<COV, TAB, MTW>(r2, sig0, sA, cA, sB, cB, A, expS, mt_lds);
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;
@@ -710,10 +806,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 }
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
-                    const int cs = s * (s + 1) / 2;                  // compile-time after unrolling
-                    const unsigned oA = __umul24(rq8[q], s + 1) + rt8[q];
-                    const unsigned oB = rtB8[q] + (unsigned)(8 * (s - P - cs));
-                    *reinterpret_cast<double *>(trb + ((rq[q] < P - s) ? oA : oB) + 8 * cs) = v[q];
+                    *lds_wptr(((rq[q] < P - s) ? trA[q] : trB[q]) + 8 * s) = v[q];
+                    trA[q] += rq8[q] + 8 * s;                        // to round s + 1
                 }
             }
         };
@@ -789,6 +883,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             static_for<0, P - 1>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int qj = j / LPS;                                 // the slot that holds pivot row j (in lane j % LPS)
+                if constexpr (PFREC && j == P / 2) load_rec();              // pidx: the NEXT task's indices by now
                 double pj;                                                  // pivot = Schur complement d_j^2
                 double ylo[RPL], yhi[RPL];                                  // LPS = 32: column j of the even / odd DPP row
                 if constexpr (LPS == 16) {
