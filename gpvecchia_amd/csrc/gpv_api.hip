@@ -659,7 +659,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                 GPV_HIP(hipEventSynchronize(pl->mt_ev[sl]));              // two evaluations ago: long done in steady state
             }
             int full = 0;
-            matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, pl->h_mt2[sl], &a.mt_base,
+            matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, cs.sA, pl->h_mt2[sl], &a.mt_base,
                              &a.mt_nseg, kMaxSeg, &full);
             a.mt_full = (a.mt_nseg > 0 && full) ? 1 : 0;
             // LDS window of the kernel (gpv_sets_kernel.hpp, mt_window_rows): the 6 octaves of s = dist/range that hold most of

@@ -249,17 +249,39 @@ __device__ inline double matern_general_tab(const BesselTab &T, double s, double
 // ---- per-launch table of h(s) = s^nu K_nu(s) e^s ------------------------------------------------------------------
 // nu is fixed inside a launch and h is smooth and slowly varying away from s = 0, so the host fits it once per
 // evaluation on the segments [2^e (1 + m/4), 2^e (1 + (m+1)/4)), m = 0..3 (segment index = the exponent and the two
-// leading mantissa bits of s: one shift), degree 12 in the Chebyshev basis: the nearest singularity (s = 0) is at least
-// 9 half-widths from a segment's centre, so the truncation error is below 18^-13 ~ 5e-17 relative.  One segment is one
-// 128-byte row {centre, 1/half-width, a_0 .. a_12, 0}.  The device evaluates h by Clenshaw's recurrence and multiplies by
-// exp(-s); distances outside the tabulated range take the series / continued-fraction path above.
+// leading mantissa bits of s: one shift).  Per segment the function is interpolated at 13 Chebyshev points (degree 12: the
+// nearest singularity, s = 0, is at least 9 half-widths from the centre, so the truncation error is below 18^-13 ~ 5e-17
+// relative) and the interpolant is stored in the MONOMIAL basis of u = (s - centre) / half-width: its coefficients decay like
+// 9^-k (Taylor radius over half-width), so Horner's rule on |u| <= 1 has no cancellation and costs 12 FMAs where Clenshaw's
+// recurrence on the Chebyshev coefficients costs 24 operations.  The caller's constant factor is multiplied in.
+// One segment is one 128-byte row {1/half-width, -centre/half-width = -(9 + 2m), scale a_0 .. scale a_12, 0}:
+// u = fma(s, row[0], row[1]).  The device multiplies by exp(-s); distances outside the tabulated range take the series /
+// continued-fraction path above.
 struct MaternTab {
     static constexpr int DEG = 12, ROW = 16;
 };
+__device__ __forceinline__ double matern_tab_poly(const double2 q0, const double2 q1, const double2 q2, const double2 q3,
+                                                  const double2 q4, const double2 q5, const double2 q6, const double2 q7,
+                                                  const double s)
+{
+    const double u = __builtin_fma(s, q0.x, q0.y);
+    double p = __builtin_fma(q7.x, u, q6.y);
+    p = __builtin_fma(p, u, q6.x);
+    p = __builtin_fma(p, u, q5.y);
+    p = __builtin_fma(p, u, q5.x);
+    p = __builtin_fma(p, u, q4.y);
+    p = __builtin_fma(p, u, q4.x);
+    p = __builtin_fma(p, u, q3.y);
+    p = __builtin_fma(p, u, q3.x);
+    p = __builtin_fma(p, u, q2.y);
+    p = __builtin_fma(p, u, q2.x);
+    p = __builtin_fma(p, u, q1.y);
+    return __builtin_fma(p, u, q1.x);
+}
 
 // *full (may be nullptr): 1 when [smin, smax] lies inside the tabulated range (nothing was cut at either end)
-inline void matern_tab_build(double nu, double smin, double smax, double *rows /* nseg x 16 */, int *base_idx, int *nseg,
-                             int max_seg, int *full = nullptr)
+inline void matern_tab_build(double nu, double smin, double smax, double scale, double *rows /* nseg x 16 */, int *base_idx,
+                             int *nseg, int max_seg, int *full = nullptr)
 {
     if (full) *full = 0;
     constexpr int N = MaternTab::DEG + 1;
@@ -275,6 +297,12 @@ inline void matern_tab_build(double nu, double smin, double smax, double *rows /
     double cs[N][N];
     for (int k = 0; k < N; ++k)
         for (int j = 0; j < N; ++j) cs[k][j] = std::cos(3.14159265358979323846 * k * (j + 0.5) / N);
+    // T_k(u) = sum_j tk[k][j] u^j (integers up to 2^11: exact)
+    double tk[N][N] = {};
+    tk[0][0] = 1.0;
+    tk[1][1] = 1.0;
+    for (int k = 2; k < N; ++k)
+        for (int j = 0; j < N; ++j) tk[k][j] = (j > 0 ? 2.0 * tk[k - 1][j - 1] : 0.0) - tk[k - 2][j];
     for (int seg = 0; seg < *nseg; ++seg) {
         const int e = e_lo + seg / 4, m = seg % 4;
         const double c = std::ldexp(1.0 + (m + 0.5) / 4.0, e), hw = std::ldexp(1.0, e - 3);
@@ -283,13 +311,19 @@ inline void matern_tab_build(double nu, double smin, double smax, double *rows /
             const double s = c + hw * cs[1][j];
             f[j] = std::exp(nu * std::log(s) + s) * bessel_k_nu(nu, s);
         }
-        double *row = rows + (size_t)seg * MaternTab::ROW;
-        row[0] = c;
-        row[1] = 1.0 / hw;
+        long double ch[N];
         for (int k = 0; k < N; ++k) {
-            double a = 0.0;
-            for (int j = 0; j < N; ++j) a += f[j] * cs[k][j];
-            row[2 + k] = a * (k == 0 ? 1.0 : 2.0) / N;
+            long double a = 0.0L;
+            for (int j = 0; j < N; ++j) a += (long double)f[j] * (long double)cs[k][j];
+            ch[k] = a * (k == 0 ? 1.0L : 2.0L) / N;
+        }
+        double *row = rows + (size_t)seg * MaternTab::ROW;
+        row[0] = 1.0 / hw;
+        row[1] = -(9.0 + 2.0 * m);                            // -centre / half-width, exact
+        for (int j = 0; j < N; ++j) {
+            long double a = 0.0L;
+            for (int k = N - 1; k >= j; --k) a += ch[k] * (long double)tk[k][j];     // smallest terms first
+            row[2 + j] = (double)(a * (long double)scale);
         }
         row[15] = 0.0;
     }

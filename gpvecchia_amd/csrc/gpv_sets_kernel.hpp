@@ -393,22 +393,7 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
     if ((unsigned)seg < (unsigned)mt_nseg) {
         const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
         const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6], q7 = row[7];
-        const double u = (s - q0.x) * q0.y, u2 = u + u;
-        // Clenshaw: b_k = a_k + 2u b_{k+1} - b_{k+2}; p = a_0 + u b_1 - b_2    (a_0 = q1.x ... a_12 = q7.x)
-        double b2 = 0.0, b1 = q7.x, b0;
-        b0 = __builtin_fma(u2, b1, q6.y) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q6.x) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q5.y) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q5.x) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q4.y) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q4.x) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q3.y) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q3.x) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q2.y) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q2.x) - b2; b2 = b1; b1 = b0;
-        b0 = __builtin_fma(u2, b1, q1.y) - b2; b2 = b1; b1 = b0;
-        const double p = __builtin_fma(u, b1, q1.x) - b2;
-        return normcon * p * exp_neg(s);
+        return matern_tab_poly(q0, q1, q2, q3, q4, q5, q6, q7, s) * exp_neg(s);       // (normcon is in the table)
     }
     return matern_general_tab(bt, s, normcon, nu);
 }
@@ -419,7 +404,7 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
 // inside the table
 template <int MTW>
 __device__ __forceinline__ double matern_table_only(const double *mt, int mt_base, int mt_nseg, int mt_win, const double *mt_lds,
-                                                    double s, double normcon)
+                                                    double s, const ExpScaled &E)
 {
     int seg = (int)(__double_as_longlong(s) >> 50) - mt_base;
     seg = seg < 0 ? 0 : (seg >= mt_nseg ? mt_nseg - 1 : seg);
@@ -438,21 +423,7 @@ __device__ __forceinline__ double matern_table_only(const double *mt, int mt_bas
         const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
         q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5]; q6 = row[6]; q7 = row[7];
     }
-    const double u = (s - q0.x) * q0.y, u2 = u + u;
-    double b2 = 0.0, b1 = q7.x, b0;
-    b0 = __builtin_fma(u2, b1, q6.y) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q6.x) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q5.y) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q5.x) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q4.y) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q4.x) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q3.y) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q3.x) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q2.y) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q2.x) - b2; b2 = b1; b1 = b0;
-    b0 = __builtin_fma(u2, b1, q1.y) - b2; b2 = b1; b1 = b0;
-    const double p = __builtin_fma(u, b1, q1.x) - b2;
-    return normcon * p * exp_neg(s);
+    return matern_tab_poly(q0, q1, q2, q3, q4, q5, q6, q7, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
 }
 
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
@@ -489,7 +460,7 @@ __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, 
 {
     if constexpr (COV == COV_MATERN_GEN && TAB) {
         const double v = matern_table_only<MTW>(A.mt, A.mt_base, A.mt_nseg, A.mt_win, mt_lds,
-                                                sqrt_pos(__builtin_fmax(r2, 2.2250738585072014e-308)) * cA, sA);
+                                                sqrt_pos(__builtin_fmax(r2, 2.2250738585072014e-308)) * cA, E);
         return (r2 == 0.0) ? sig0 : v;                               // src/Matern.cpp:76
     }
     if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
@@ -540,7 +511,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     Lds &L = lds_all[wv];
 
     const double sig0 = A.sig0, sA = A.sA, cA = A.cA, sB = A.sB, cB = A.cB;
-    const ExpScaled expS = exp_scaled_setup(sA);       // closed-form Matern families: sigma^2 exp(-t) (cov_closed)
+    // closed-form Matern families: sigma^2 exp(-t) (cov_closed); general nu: the table carries the constant factor
+    const ExpScaled expS = exp_scaled_setup(COV == COV_MATERN_GEN ? 1.0 : sA);
     const unsigned long long setmask = (LPS == 64) ? ~0ull : (((1ull << LPS) - 1ull) << (sub * LPS));
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
