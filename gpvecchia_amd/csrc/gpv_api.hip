@@ -645,7 +645,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         bessel_tab_fill(cs.sB, a.bt);
         static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
         if (!no_tab && pl->dist_min > 0.0 && pl->dist_max >= pl->dist_min) {
-            constexpr int kMaxSeg = 320;                                   // 80 octaves
+            constexpr int kMaxSeg = 80 * MaternTab::SPO;                   // 80 octaves
             // the table travels in kernel-argument style: two pinned host staging buffers and two device copies used
             // alternately, guarded by an event each, so that building the table for this evaluation never waits for the
             // stream (the previous evaluation may still be reading the other copy)
@@ -666,8 +666,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             // the plan's point-to-neighbour distances, shifted up half an octave for the neighbour-to-neighbour pairs
             a.mt_win = 0;
             if (a.mt_full && !pl->dist_hist.empty()) {
-                const int e_lo = (a.mt_base >> 2) - 1023;                 // binary exponent of the table's first segment
-                const int noct = a.mt_nseg / 4;
+                const int e_lo = (a.mt_base >> MaternTab::LSPO) - 1023;   // binary exponent of the table's first segment
+                const int noct = a.mt_nseg / MaternTab::SPO;
                 const double sh = std::log2(cs.cA) + 0.5;
                 std::vector<double> H((size_t)noct, 0.0);
                 for (int ex = 0; ex < 2200; ++ex) {
@@ -683,7 +683,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                     if (m6 > best) { best = m6; bo = o; }
                     if (o + 6 > noct) break;
                 }
-                a.mt_win = 4 * bo;
+                a.mt_win = MaternTab::SPO * bo;
             }
             if (a.mt_nseg > 0) {
                 GPV_HIP(hipMemcpyAsync(pl->d_mt2[sl], pl->h_mt2[sl], sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,

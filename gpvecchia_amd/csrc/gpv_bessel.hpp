@@ -248,64 +248,69 @@ __device__ inline double matern_general_tab(const BesselTab &T, double s, double
 
 // ---- per-launch table of h(s) = s^nu K_nu(s) e^s ------------------------------------------------------------------
 // nu is fixed inside a launch and h is smooth and slowly varying away from s = 0, so the host fits it once per
-// evaluation on the segments [2^e (1 + m/4), 2^e (1 + (m+1)/4)), m = 0..3 (segment index = the exponent and the two
-// leading mantissa bits of s: one shift).  Per segment the function is interpolated at 13 Chebyshev points (degree 12: the
-// nearest singularity, s = 0, is at least 9 half-widths from the centre, so the truncation error is below 18^-13 ~ 5e-17
+// evaluation on the segments [2^e (1 + m/8), 2^e (1 + (m+1)/8)), m = 0..7 (segment index = the exponent and the three
+// leading mantissa bits of s: one shift).  Per segment the function is interpolated at 11 Chebyshev points (degree 10: the
+// nearest singularity, s = 0, is at least 17 half-widths from the centre, so the truncation error is below 34^-11 ~ 1.4e-17
 // relative) and the interpolant is stored in the MONOMIAL basis of u = (s - centre) / half-width: its coefficients decay like
-// 9^-k (Taylor radius over half-width), so Horner's rule on |u| <= 1 has no cancellation and costs 12 FMAs where Clenshaw's
-// recurrence on the Chebyshev coefficients costs 24 operations.  The caller's constant factor is multiplied in.
-// One segment is one 128-byte row {1/half-width, -centre/half-width = -(9 + 2m), scale a_0 .. scale a_12, 0}:
-// u = fma(s, row[0], row[1]).  The device multiplies by exp(-s); distances outside the tabulated range take the series /
-// continued-fraction path above.
+// 17^-k (Taylor radius over half-width), so Horner's rule on |u| <= 1 has no cancellation and costs 10 FMAs.  u needs no
+// table entry: with s = 2^e (1 + f), u = 2 frac(8 f) - 1, i.e. the mantissa shifted left by three bits, read as a number
+// g in [1, 2): u = 2 g - 3.  The caller's constant factor is multiplied into the coefficients.
+// One segment is one 96-byte row {scale a_0 .. scale a_10, 0}: what the set kernel pays for per pair is LDS bandwidth
+// (rows are gathered by every lane's own distance), so the row is as short as the accuracy allows: round 2 began with
+// four segments per octave at degree 12 in the Chebyshev basis (128-byte rows, Clenshaw).  The device multiplies by
+// exp(-s); distances outside the tabulated range take the series / continued-fraction path above.
 struct MaternTab {
-    static constexpr int DEG = 12, ROW = 16;
+    static constexpr int DEG = 10, ROW = 12, LSPO = 3, SPO = 1 << LSPO;     // degree, doubles per row, segments per octave
 };
-__device__ __forceinline__ double matern_tab_poly(const double2 q0, const double2 q1, const double2 q2, const double2 q3,
-                                                  const double2 q4, const double2 q5, const double2 q6, const double2 q7,
-                                                  const double s)
+__device__ __forceinline__ int matern_tab_segment(const double s, const int base)
 {
-    const double u = __builtin_fma(s, q0.x, q0.y);
-    double p = __builtin_fma(q7.x, u, q6.y);
-    p = __builtin_fma(p, u, q6.x);
-    p = __builtin_fma(p, u, q5.y);
-    p = __builtin_fma(p, u, q5.x);
-    p = __builtin_fma(p, u, q4.y);
+    return (int)(__double_as_longlong(s) >> (52 - MaternTab::LSPO)) - base;
+}
+__device__ __forceinline__ double matern_tab_poly(const double2 q0, const double2 q1, const double2 q2, const double2 q3,
+                                                  const double2 q4, const double2 q5, const double s)
+{
+    const unsigned long long gb = (((unsigned long long)__double_as_longlong(s) << MaternTab::LSPO) & 0x000FFFFFFFFFFFFFull) |
+                                  0x3FF0000000000000ull;
+    const double u = __builtin_fma(__longlong_as_double((long long)gb), 2.0, -3.0);
+    double p = __builtin_fma(q5.x, u, q4.y);
     p = __builtin_fma(p, u, q4.x);
     p = __builtin_fma(p, u, q3.y);
     p = __builtin_fma(p, u, q3.x);
     p = __builtin_fma(p, u, q2.y);
     p = __builtin_fma(p, u, q2.x);
     p = __builtin_fma(p, u, q1.y);
-    return __builtin_fma(p, u, q1.x);
+    p = __builtin_fma(p, u, q1.x);
+    p = __builtin_fma(p, u, q0.y);
+    return __builtin_fma(p, u, q0.x);
 }
 
 // *full (may be nullptr): 1 when [smin, smax] lies inside the tabulated range (nothing was cut at either end)
-inline void matern_tab_build(double nu, double smin, double smax, double scale, double *rows /* nseg x 16 */, int *base_idx,
+inline void matern_tab_build(double nu, double smin, double smax, double scale, double *rows /* nseg x ROW */, int *base_idx,
                              int *nseg, int max_seg, int *full = nullptr)
 {
     if (full) *full = 0;
-    constexpr int N = MaternTab::DEG + 1;
+    constexpr int N = MaternTab::DEG + 1, SPO = MaternTab::SPO;
     int e_lo = (int)std::floor(std::log2(smin)), e_hi = (int)std::floor(std::log2(smax));
     bool cut = false;
     if (e_lo < -200) { e_lo = -200; cut = true; }
     if (e_hi > 8) { e_hi = 8; cut = true; }                   // s < 512: K_nu(s) e^s stays in range; beyond, the value is ~0 anyway
     if (e_hi < e_lo) { *nseg = 0; *base_idx = 0; return; }
-    if ((e_hi - e_lo + 1) * 4 > max_seg) { e_lo = e_hi + 1 - max_seg / 4; cut = true; }
+    if ((e_hi - e_lo + 1) * SPO > max_seg) { e_lo = e_hi + 1 - max_seg / SPO; cut = true; }
     if (full) *full = cut ? 0 : 1;
-    *base_idx = (e_lo + 1023) << 2;
-    *nseg = (e_hi - e_lo + 1) * 4;
+    *base_idx = (e_lo + 1023) << MaternTab::LSPO;
+    *nseg = (e_hi - e_lo + 1) * SPO;
     double cs[N][N];
     for (int k = 0; k < N; ++k)
         for (int j = 0; j < N; ++j) cs[k][j] = std::cos(3.14159265358979323846 * k * (j + 0.5) / N);
-    // T_k(u) = sum_j tk[k][j] u^j (integers up to 2^11: exact)
+    // T_k(u) = sum_j tk[k][j] u^j (integers up to 2^9: exact)
     double tk[N][N] = {};
     tk[0][0] = 1.0;
     tk[1][1] = 1.0;
     for (int k = 2; k < N; ++k)
         for (int j = 0; j < N; ++j) tk[k][j] = (j > 0 ? 2.0 * tk[k - 1][j - 1] : 0.0) - tk[k - 2][j];
     for (int seg = 0; seg < *nseg; ++seg) {
-        const int e = e_lo + seg / 4, m = seg % 4;
-        const double c = std::ldexp(1.0 + (m + 0.5) / 4.0, e), hw = std::ldexp(1.0, e - 3);
+        const int e = e_lo + seg / SPO, m = seg % SPO;
+        const double c = std::ldexp(1.0 + (m + 0.5) / SPO, e), hw = std::ldexp(1.0, e - 1 - MaternTab::LSPO);
         double f[N];
         for (int j = 0; j < N; ++j) {
             const double s = c + hw * cs[1][j];
@@ -318,14 +323,12 @@ inline void matern_tab_build(double nu, double smin, double smax, double scale, 
             ch[k] = a * (k == 0 ? 1.0L : 2.0L) / N;
         }
         double *row = rows + (size_t)seg * MaternTab::ROW;
-        row[0] = 1.0 / hw;
-        row[1] = -(9.0 + 2.0 * m);                            // -centre / half-width, exact
         for (int j = 0; j < N; ++j) {
             long double a = 0.0L;
             for (int k = N - 1; k >= j; --k) a += ch[k] * (long double)tk[k][j];     // smallest terms first
-            row[2 + j] = (double)(a * (long double)scale);
+            row[j] = (double)(a * (long double)scale);
         }
-        row[15] = 0.0;
+        for (int j = N; j < MaternTab::ROW; ++j) row[j] = 0.0;
     }
 }
 

@@ -41,8 +41,8 @@ struct SetArgs {
     double sig0, sA, cA, sB, cB;
     double nug_scalar;       // constant nugget (R/createU.R:74) when nuggets == nullptr
     BesselTab bt;            // COV_MATERN_GEN: order-dependent constants of K_nu (gpv_bessel.hpp), filled on the host
-    const double *mt;        // COV_MATERN_GEN: [mt_nseg][16] table of s^nu K_nu(s) e^s (device), or nullptr
-    int mt_base, mt_nseg;    //   segment of s = (bits(s) >> 50) - mt_base
+    const double *mt;        // COV_MATERN_GEN: [mt_nseg][MaternTab::ROW] table of normcon s^nu K_nu(s) e^s (device), or nullptr
+    int mt_base, mt_nseg;    //   segment of s = (bits(s) >> 49) - mt_base (gpv_bessel.hpp, matern_tab_segment)
     int mt_full;             //   1: the table covers every pair distance of the plan (no range test per pair needed)
     int mt_win;              //   first table row of the window the workgroups keep in LDS (where the distances concentrate)
 };

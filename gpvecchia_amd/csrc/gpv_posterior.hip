@@ -183,7 +183,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
 
 template <int WPC, int MODE = 0>
 __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level_kernel(const PostArgs A, int first, int count,
-                                                                                        double *tailpart, int tail_base)
+                                                                                        double *toppart, int top_base)
 {
     extern __shared__ double tile_all[];
     const int lane = threadIdx.x & 63;
@@ -195,7 +195,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     // set kernel's index stream and location records out of the Infinity Cache between evaluations
     const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
     const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
-    post_column<WPC, MODE>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : tailpart + 66 * (size_t)(first + w - tail_base));
+    post_column<WPC, MODE>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
 }
 
 // C <- (B, 0) from the row-major Lentries, heads <- (a, 0): one thread per compact entry, coalesced writes

@@ -186,7 +186,7 @@ constexpr int blocks_per_cu()
 // octaves chosen by the host where the plan's pair distances concentrate).  From global memory the 8 x 16-byte row
 // gathers per pair make the kernel texture-address bound (5.2 ms against 1.55 ms for a closed form at n = 1e6, m = 30);
 // the window takes exactly the LDS the instantiation leaves unused at its occupancy, so it never costs a workgroup.
-constexpr int kMtRowLds = 18;                       // doubles per LDS row: 144-byte stride => 16 distinct rows hit 16 distinct bank quads
+constexpr int kMtRowLds = MaternTab::ROW;           // doubles per LDS row (96 bytes)
 template <int P, int D, int COV>
 constexpr int mt_window_rows()
 {
@@ -194,9 +194,9 @@ constexpr int mt_window_rows()
     const int w = wpb<P, D, COV>();
     const long left = 163840 / blocks_per_cu<P, D, COV>() - (long)sizeof(SetsLds<P, D, COV>) * w - 64;
     long rows = left / (kMtRowLds * 8);
-    rows = rows > 32 ? 32 : rows;
-    rows &= ~3L;                                    // whole octaves
-    return rows < 8 ? 0 : (int)rows;
+    rows = rows > 8 * MaternTab::SPO ? 8 * MaternTab::SPO : rows;
+    rows &= ~(long)(MaternTab::SPO - 1);            // whole octaves
+    return rows < 2 * MaternTab::SPO ? 0 : (int)rows;
 }
 
 // Lanes of one wavefront exchange data through LDS.  The hardware executes a wave's LDS
@@ -389,11 +389,11 @@ __device__ __forceinline__ double rcp_safe(double x)
 __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_base, int mt_nseg, const BesselTab &bt,
                                                      double s, double normcon, double nu)
 {
-    const int seg = (int)(__double_as_longlong(s) >> 50) - mt_base;
+    const int seg = matern_tab_segment(s, mt_base);
     if ((unsigned)seg < (unsigned)mt_nseg) {
         const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
-        const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5], q6 = row[6], q7 = row[7];
-        return matern_tab_poly(q0, q1, q2, q3, q4, q5, q6, q7, s) * exp_neg(s);       // (normcon is in the table)
+        const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
+        return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg(s);               // (normcon is in the table)
     }
     return matern_general_tab(bt, s, normcon, nu);
 }
@@ -406,24 +406,24 @@ template <int MTW>
 __device__ __forceinline__ double matern_table_only(const double *mt, int mt_base, int mt_nseg, int mt_win, const double *mt_lds,
                                                     double s, const ExpScaled &E)
 {
-    int seg = (int)(__double_as_longlong(s) >> 50) - mt_base;
+    int seg = matern_tab_segment(s, mt_base);
     seg = seg < 0 ? 0 : (seg >= mt_nseg ? mt_nseg - 1 : seg);
-    double2 q0, q1, q2, q3, q4, q5, q6, q7;
+    double2 q0, q1, q2, q3, q4, q5;
     bool from_lds = false;
     if constexpr (MTW > 0) {
         const int rel = seg - mt_win;
         const bool in = (unsigned)rel < (unsigned)MTW;
         if (__builtin_amdgcn_ballot_w64(!in) == 0) {                // wave uniform: every lane's segment sits in the LDS window
             const double2 *row = reinterpret_cast<const double2 *>(mt_lds + rel * kMtRowLds);
-            q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5]; q6 = row[6]; q7 = row[7];
+            q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5];
             from_lds = true;
         }
     }
     if (!from_lds) {
         const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
-        q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5]; q6 = row[6]; q7 = row[7];
+        q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5];
     }
-    return matern_tab_poly(q0, q1, q2, q3, q4, q5, q6, q7, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
+    return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
 }
 
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
@@ -493,8 +493,9 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     __shared__ __attribute__((aligned(16))) double mt_lds[MTW > 0 ? MTW * kMtRowLds : 2];
     if constexpr (MTW > 0) {
         if (A.mt_full) {                                 // rows [mt_win, mt_win + MTW) of this launch's table (clamped at its end)
-            for (int t = threadIdx.x; t < MTW * 8; t += W * 64) {
-                const int r = t >> 3, c = t & 7;
+            constexpr int RC = MaternTab::ROW / 2;           // 16-byte pieces per row
+            for (int t = threadIdx.x; t < MTW * RC; t += W * 64) {
+                const int r = t / RC, c = t - r * RC;
                 const int src = (A.mt_win + r < A.mt_nseg) ? A.mt_win + r : A.mt_nseg - 1;
                 reinterpret_cast<double2 *>(mt_lds + r * kMtRowLds)[c] = reinterpret_cast<const double2 *>(A.mt + (size_t)src * MaternTab::ROW)[c];
             }
