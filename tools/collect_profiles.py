@@ -3,6 +3,7 @@ profiles/: <name>_bench.json, <name>_kernel_stats.csv, <name>_pmc_pass<i>.csv (s
 and r02_pmc_traffic.json (the per-launch HBM traffic bench.py quotes while the kernel source hash matches).
 
     python tools/collect_profiles.py gpurun_out/r02 r02
+    python tools/collect_profiles.py gpurun_out/r02C4 r02_C4 notraffic     (another config: everything but r02_pmc_traffic.json)
 """
 import csv
 import glob
@@ -50,7 +51,7 @@ if "GRBM_GUI_ACTIVE" in tot:
         "write_bytes": tot.get("WRITE_SIZE", 0) * 1024,
     }
 json.dump(tot, open(os.path.join(P, name + "_pmc_summary.json"), "w"), indent=1)
-if "FETCH_SIZE" in tot:
+if "FETCH_SIZE" in tot and not (len(sys.argv) > 3 and sys.argv[3] == "notraffic"):
     ksrc = open(os.path.join(ROOT, "gpvecchia_amd", "csrc", "gpv_sets_kernel.hpp"), "rb").read()
     json.dump({
         "hbm_bytes_per_launch": (2.0 * tot["FETCH_SIZE"] + tot.get("WRITE_SIZE", 0)) * 1024,
