@@ -315,7 +315,8 @@ __device__ __forceinline__ lds_wdouble *lds_wptr(unsigned a) { return (lds_wdoub
 //   * k = round(-t log2 e) is taken from the low mantissa bits of -t log2 e + 1.5 * 2^52 and added straight into the
 //     exponent field of the result (no v_cvt_i32_f64, no v_ldexp_f64).  t is clamped so that the result stays a normal
 //     number (tmax: 700, less what a scale below 1 takes from the exponent range); past the clamp the value is
-//     scale * e^-tmax < 1e-300 instead of 0.
+//     scale * e^-tmax ~ 2^-1010 instead of something smaller: below 2^-65 of the block's diagonal (>= scale) for any
+//     scale >= 2^-945 ~ 1e-284, i.e. invisible in FP64 (tests: sigma^2 from 1e-200 to 1e200).
 struct ExpScaled {
     double c[12];                                   // scale * (c11 .. c2), then scale, scale
     double tmax;

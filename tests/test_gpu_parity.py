@@ -138,6 +138,29 @@ def test_covariance_families_and_loglik(covmodel, cp, cond):
     assert abs(ll - ll_ref) <= LL_RTOL * abs(ll_ref)
 
 
+@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5, 1.2])
+@pytest.mark.parametrize("sig2", [1e-200, 1e-30, 1e-6, 1e6, 1e30, 1e200])
+def test_variance_scale_extremes(nu, sig2):
+    # the closed-form Matern families leave the kernel's exp() already multiplied by sigma^2 (coefficients scaled once per
+    # wavefront, exponent added into the result's exponent field, argument clamped so that the result stays normal): the
+    # factor of U must scale like 1/sigma and the likelihood must follow the oracle over the whole exponent range;
+    # the far pairs of a short range (t = sqrt(2 nu) d / range up to ~ 2000) exercise the clamp
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, m = 600, 15
+    locs, z, va = _case(n, m, 2, 77, "z", ordering="maxmin")
+    z = z * np.sqrt(sig2)
+    pva = _to_product_va(va)
+    for rng_ in (0.15, 0.001):
+        cp, tau = [sig2, rng_, nu], 0.1 * sig2
+        refU = R.createU(va, cp, tau)
+        U = G.createU(pva, cp, tau)
+        assert _row_err(U["Lentries"], refU["U_entries"]["Lentries"]) < ROW_TOL
+        ll_ref = R.vecchia_likelihood_U(z, refU)
+        ll = G.vecchia_likelihood(z, pva, cp, tau)
+        assert np.isfinite(ll) and abs(ll - ll_ref) <= LL_RTOL * max(abs(ll_ref), 1.0)
+
+
 def test_fused_sums_match_oracle_closed_form():
     G = _need_gpu()
     from oracle import r_side as R
