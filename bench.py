@@ -128,6 +128,16 @@ def _free_port():
     return p
 
 
+def kernel_code_sha256():
+    """Hash of the conditioning-set kernel's CODE (gpv_sets_kernel.hpp with comments and whitespace removed): the PMC traffic
+    figure in profiles/ is quoted only while it was measured on the code in this tree."""
+    import re
+    src = open(os.path.join(ROOT, "gpvecchia_amd", "csrc", "gpv_sets_kernel.hpp"), encoding="utf-8").read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    return hashlib.sha256("".join(src.split()).encode()).hexdigest()
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start the N ranks as fresh processes.  Nothing in this process has touched
     the GPU (torch.cuda.device_count() does not initialise it), and nothing is exec'ed."""
@@ -325,12 +335,11 @@ def main():
         traffic = None
         tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
         if os.path.exists(tf) and args.config == "C3" and not custom and world == 1 and args.mode == "L":
-            # HBM bytes per launch from the PMC passes of tools/pmc_traffic.sh; quoted only while the kernel source
+            # HBM bytes per launch from the PMC passes of tools/profile_round.sh; quoted only while the kernel code
             # they were measured on is the one in this tree
             try:
                 tj = json.load(open(tf))
-                src = open(os.path.join(ROOT, "gpvecchia_amd", "csrc", "gpv_sets_kernel.hpp"), "rb").read()
-                if tj.get("kernel_source_sha256") == hashlib.sha256(src).hexdigest():
+                if tj.get("kernel_code_sha256") == kernel_code_sha256():
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
