@@ -73,7 +73,23 @@ class Plan:
         z = np.ascontiguousarray(z_ord, dtype=np.float64)
         if z.shape[0] != self.Nlocs:
             raise ValueError("z_ord must have one entry per ordered location")
+        self._user_z = None                              # whatever set_user_data remembered is no longer on the device
         L.check(L.lib().gpv_plan_set_data(self._h, L.dptr(z)), "gpv_plan_set_data")
+
+    def set_user_data(self, z, ord_z):
+        """set_data(z[ord_z - 1]) unless exactly this z is the data already on the device: an optimiser evaluates the
+        likelihood of ONE data vector hundreds of times (R/vecchia_wrappers.R:72-93), and reordering and uploading 8 MB
+        per call costs more than the evaluation itself at n = 1e6.  The comparison is by content, against a private copy."""
+        prev = getattr(self, "_user_z", None)
+        if prev is not None and prev.shape == z.shape and np.array_equal(prev, z):
+            return False
+        self.set_data(z[ord_z - 1])
+        self._user_z = np.array(z, dtype=np.float64, copy=True)
+        return True
+
+    def invalidate_data(self):
+        """Called by code that changes the plan's data behind set_data (the Vecchia-Laplace device loop)."""
+        self._user_z = None
 
     def eval(self, covmodel, covparms, nuggets, flags, stream=None, d_sums_out=None):
         cp = np.ascontiguousarray(covparms, dtype=np.float64)
@@ -652,12 +668,17 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
     va = vecchia_approx
     if va["cond_yz"] == "zy":
         warnings.warn("cond.yz='zy' will produce a poor likelihood approximation. Use 'SGV' instead.")
-    z, nug = _removeNAs(z, nuggets)
+    z_in = np.asarray(z, dtype=np.float64)
+    nug_in = np.atleast_1d(np.asarray(nuggets, dtype=np.float64))
+    if nug_in.size == 1 and not np.isnan(z_in.sum()):    # nothing for removeNAs to do (a NaN anywhere makes the sum NaN)
+        z, nug = z_in, nug_in
+    else:
+        z, nug = _removeNAs(z, nuggets)
     n = int(np.sum(va["obs"]))
     plain = n == va["locsord"].shape[0]                  # every row of locsord observed: the fused device paths apply
     if plain and va["cond_yz"] in ("z", "false") and isinstance(covmodel, str) and not np.any(nug == 0):
         plan = _plan_for(va, device)
-        plan.set_data(z[va["ord_z"] - 1])
+        plan.set_user_data(z, va["ord_z"])
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_LOGLIK_Z)
         return loglik_z_from_sums(plan.sums(), n)
     if plain and va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0) and \
@@ -667,7 +688,7 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         plan = _plan_for(va, device)
         if not plan.has_posterior:
             plan.build_posterior()
-        plan.set_data(z[va["ord_z"] - 1])
+        plan.set_user_data(z, va["ord_z"])
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_DENOM)
         return loglik_from_sums(plan.sums(), n)
     U_obj = createU(va, covparms, nug, covmodel, device=device)

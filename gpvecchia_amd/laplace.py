@@ -109,6 +109,7 @@ def _posterior_VL_device(z, va, model, covparms, covmodel, likparms, max_iter, c
     zo = np.ascontiguousarray(z[ordz])
     pmo = np.ascontiguousarray(prior_mean[ordz])
     yo = np.ascontiguousarray(y_init[ordz])
+    plan.invalidate_data()                               # the loop writes pseudo-data into the plan's data arrays
     L.check(L.lib().gpv_plan_vl_begin(plan._h, _DEVICE_MODELS[model], L.dptr(lp), L.dptr(zo), L.dptr(pmo), L.dptr(yo)),
             "gpv_plan_vl_begin")
     cp = np.ascontiguousarray(covparms, dtype=np.float64)

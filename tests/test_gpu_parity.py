@@ -721,6 +721,35 @@ def test_dense_top_block_of_posterior_pass_matches_level_schedule():
 
 
 @pytest.mark.parametrize("cond", ["SGV", "z"])
+def test_likelihood_reuses_resident_data_only_when_it_is_the_same(cond):
+    # vecchia_likelihood keeps the data vector on the device between calls (an optimiser passes the same z every time); the
+    # check is by content: an in-place change of z, other data set by vecchia_prediction, or a Vecchia-Laplace run in
+    # between must all be noticed
+    G = _need_gpu()
+    rng = np.random.default_rng(3)
+    n, m = 2000, 12
+    locs = rng.random((n, 2)); z = rng.standard_normal(n); z2 = rng.standard_normal(n)
+    cp, tau = [1.2, 0.1, 1.5], 0.2
+    va = G.vecchia_specify(locs, m, cond_yz=cond)
+    fresh = lambda zz: G.vecchia_likelihood(zz, G.vecchia_specify(locs, m, cond_yz=cond), cp, tau)
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    plan = va[("_plan", 0)]
+    assert plan.set_user_data(z, va["ord_z"]) is False                 # second call: nothing uploaded
+    assert G.vecchia_likelihood(z, va, cp, tau) == ll
+    z[5] += 1.0                                                        # same object, new content
+    ll_b = G.vecchia_likelihood(z, va, cp, tau)
+    assert ll_b != ll and ll_b == fresh(z)
+    G.vecchia_prediction(z2, va, cp, tau)                              # puts z2 on the device
+    assert G.vecchia_likelihood(z, va, cp, tau) == ll_b
+    if cond == "SGV":
+        zc = rng.poisson(1.5, n).astype(float)
+        G.calculate_posterior_VL(zc, va, "poisson", cp)                # the device loop overwrites the plan's data
+        assert G.vecchia_likelihood(z, va, cp, tau) == ll_b
+    zn = z.copy(); zn[7] = np.nan                                      # missing value: the removeNAs path (R/vecchia_likelihood.R:45-58)
+    assert np.isfinite(G.vecchia_likelihood(zn, va, cp, tau)) and G.vecchia_likelihood(z, va, cp, tau) == ll_b
+
+
+@pytest.mark.parametrize("cond", ["SGV", "z"])
 def test_posterior_mean_on_device(cond):
     # vecchia_prediction(..., 'meanmat'): createU + U2V + vecchia_mean (R/vecchia_prediction.R:17-56,118-142)
     G = _need_gpu()
