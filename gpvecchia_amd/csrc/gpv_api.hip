@@ -234,9 +234,10 @@ struct gpv_plan {
     int4 *d_colrec = nullptr, *d_rowrec = nullptr;
     uint8_t *d_tp = nullptr;
     double2 *d_C = nullptr;
+    int32_t *d_cboff = nullptr, *d_cdel = nullptr;   // block offsets in d_C (Morton order of the locations), and cboff - colptr
     int64_t post_nnz = 0;
     uint8_t *d_cslot = nullptr;
-    double *d_avec = nullptr, *d_tvec = nullptr, *d_logr = nullptr, *d_post_part = nullptr,
+    double *d_avec = nullptr, *d_tvec = nullptr, *d_rdiag = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
     // the posterior pass as a captured HIP graph (one per {denominator, denominator + mean}): ~140 (280) launches of a few
@@ -312,7 +313,7 @@ int gpv_plan_destroy(gpv_plan *pl)
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
-                    pl->d_C, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_logr, pl->d_post_part, pl->d_zuser,
+                    pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags};
     for (auto &g : pl->pgraph)
@@ -712,20 +713,20 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         PostArgs pa;
         pa.colptr = pl->d_colptr; pa.crow = pl->d_crow;
         pa.colrec = pl->d_colrec; pa.rowrec = pl->d_rowrec; pa.tp = pl->d_tp;
-        pa.C = pl->d_C; pa.z = pl->d_zuser;
+        pa.C = pl->d_C; pa.cboff = pl->d_cboff; pa.z = pl->d_zuser;
         pa.nuggets = pl->d_nug_post;
         pa.nug_scalar = 0.0;
-        pa.tvec = pl->d_tvec; pa.logr = pl->d_logr; pa.ld = pl->P;
+        pa.tvec = pl->d_tvec; pa.rdiag = pl->d_rdiag; pa.ld = pl->P;
         const bool want_mean = (flags & GPV_WANT_MEAN) != 0;
         auto enqueue = [&]() -> hipError_t {
             hipError_t e = launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot,
-                                                    pl->Nlocs, pl->post_nnz, pl->d_C, st);
+                                                    pl->d_cdel, pl->Nlocs, pl->post_nnz, pl->d_C, st);
             for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr.size(); ++lv)
                 e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st);
             if (e == hipSuccess && pl->top_K > 0)
                 e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, st);
             if (e == hipSuccess)
-                e = launch_sum_pair(pl->d_logr, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st);
+                e = launch_sum_pair(pl->d_rdiag, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st);
             if (want_mean) {
                 if (e == hipSuccess)
                     e = launch_mean_head(pa, pl->d_order2, pl->d_u, pl->d_levptr2, pl->mean_head_levels, st);
@@ -904,17 +905,38 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     std::vector<int32_t> pos(pl->levptr.begin(), pl->levptr.end() - 1), order((size_t)n);
     for (int64_t k = n - 1; k >= K; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
     for (int64_t k = 0; k < K; ++k) order[(size_t)(n - K + k)] = (int32_t)k;      // the top block's records: after the schedule
-    // longest row lists first inside a level (they bound the level's duration)
-    for (int32_t l = 0; l <= maxlev; ++l)
-        std::stable_sort(order.begin() + pl->levptr[(size_t)l], order.begin() + pl->levptr[(size_t)l + 1],
-                         [&](int32_t a, int32_t b) {
-                             return rowptr[(size_t)a + 1] - rowptr[(size_t)a] > rowptr[(size_t)b + 1] - rowptr[(size_t)b];
-                         });
+    // The compact blocks are laid out in the Morton order of the locations (the internal order of the plan's location
+    // records): a column gathers from the columns of the points that condition on it, its spatial neighbours, whose blocks
+    // then share cache lines and L2 sets instead of being scattered by a maxmin ordering.
+    std::vector<int32_t> cboff((size_t)n), cdel((size_t)n);
+    {
+        std::vector<int32_t> inv((size_t)n);
+        const bool have_pos = pl->h_newpos.size() == (size_t)n;
+        for (int64_t k = 0; k < n; ++k) inv[(size_t)(have_pos ? pl->h_newpos[(size_t)k] : (int32_t)k)] = (int32_t)k;
+        int64_t off = 0;
+        for (int64_t r = 0; r < n; ++r) {
+            const int32_t k = inv[(size_t)r];
+            cboff[(size_t)k] = (int32_t)off;
+            cdel[(size_t)k] = (int32_t)(off - colptr[(size_t)k]);
+            off += colptr[(size_t)k + 1] - colptr[(size_t)k] + 1;
+        }
+    }
+    // inside a level: wide levels in Morton order too (concurrent wavefronts then work in the same neighbourhood), narrow
+    // ones longest row lists first (they bound the level's duration)
+    for (int32_t l = 0; l <= maxlev; ++l) {
+        const auto b0 = order.begin() + pl->levptr[(size_t)l], e0 = order.begin() + pl->levptr[(size_t)l + 1];
+        if (e0 - b0 > 2048 && pl->h_newpos.size() == (size_t)n)
+            std::sort(b0, e0, [&](int32_t a, int32_t b) { return pl->h_newpos[(size_t)a] < pl->h_newpos[(size_t)b]; });
+        else
+            std::stable_sort(b0, e0, [&](int32_t a, int32_t b) {
+                return rowptr[(size_t)a + 1] - rowptr[(size_t)a] > rowptr[(size_t)b + 1] - rowptr[(size_t)b];
+            });
+    }
     std::vector<int4> colrec(2 * (size_t)n), rowrec(nnz);
     for (int64_t i = 0; i < n; ++i) {
         const int32_t k = order[(size_t)i];
         const int32_t b0 = colptr[(size_t)k], cn = colptr[(size_t)k + 1] - b0;
-        colrec[2 * (size_t)i] = make_int4(k, b0 + k, cn, rowptr[(size_t)k]);
+        colrec[2 * (size_t)i] = make_int4(k, cboff[(size_t)k], cn, rowptr[(size_t)k]);
         // .y: end of the row-list entries whose column lies in the top block (row lists ascend: a prefix)
         int32_t qt = rowptr[(size_t)k];
         if ((int64_t)k < K)
@@ -926,7 +948,7 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
         const int32_t b0 = colptr[(size_t)c], cn = colptr[(size_t)c + 1] - b0;
         for (int32_t e = 0; e < cn; ++e) {
             const size_t q = (size_t)qof[(size_t)(b0 + e)];               // the pair (row crow[b0+e], column c)
-            rowrec[q] = make_int4(b0 + (int32_t)c, tptr[q], e | ((e + 1 < cn ? e + 1 : 0) << 8), 0);
+            rowrec[q] = make_int4(cboff[(size_t)c], tptr[q], e | ((e + 1 < cn ? e + 1 : 0) << 8), 0);
             ccol[(size_t)(b0 + e)] = (int32_t)c;
         }
     }
@@ -964,6 +986,8 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if ((rc = up((void **)&pl->d_rowrec, rowrec.data(), rowrec.size() * sizeof(int4))) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_tp, tp.data(), tp.size())) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_ccol, ccol.data(), nnz * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_cboff, cboff.data(), cboff.size() * 4)) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_cdel, cdel.data(), cdel.size() * 4)) != GPV_OK) return rc;
     if (pl->d_C) { (void)hipFree(pl->d_C); pl->d_C = nullptr; }
     GPV_HIP(hipMalloc((void **)&pl->d_C, sizeof(double2) * (nnz + (size_t)n)));
     pl->post_nnz = (int64_t)nnz;
@@ -983,7 +1007,7 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     for (auto &g : pl->pgraph)                                         // the schedule may have changed
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (!pl->d_tvec) GPV_HIP(hipMalloc((void **)&pl->d_tvec, nd));
-    if (!pl->d_logr) GPV_HIP(hipMalloc((void **)&pl->d_logr, nd));
+    if (!pl->d_rdiag) GPV_HIP(hipMalloc((void **)&pl->d_rdiag, nd));
     if (!pl->d_u) GPV_HIP(hipMalloc((void **)&pl->d_u, nd));
     if (!pl->d_mu) GPV_HIP(hipMalloc((void **)&pl->d_mu, nd));
     if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 512));

@@ -84,17 +84,20 @@ struct PostArgs {
     const int4 *colrec;      // [n][2]
     const int4 *rowrec;      // [nnz]
     const uint8_t *tp;
-    double2 *C;              // [nnz + n] compact blocks
+    double2 *C;              // [nnz + n] compact blocks {(a_k, t_k), (B, R) of the column's entries}, laid out in the Morton
+                             // order of the locations: the columns a column gathers from are its spatial neighbours
+    const int32_t *cboff;    // [n] offset of column k's block in C
     const double *z;         // [n] ordered data
     const double *nuggets;   // [n] ordered nuggets or nullptr
     double nug_scalar;
     double *tvec;            // [n] solution of R t = z2
-    double *logr;            // [n] log R_kk
+    double *rdiag;           // [n] R_kk (the logarithms are taken by the reduction that sums them)
     int ld;                  // row length of Lentries (bounds the entries per column)
 };
 // C <- (Lentries, a): ccol/cslot give column and Lentries slot of every compact entry
+// cdel[c] = cboff[c] - colptr[c]
 hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
-                                    const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C, hipStream_t s);
+                                    const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, hipStream_t s);
 // columns [first, first+count) of the level-ordered records; leaves = the level's row lists hold the column only (level 0)
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, hipStream_t s);
 // posterior mean (R/vecchia_prediction.R:118-126): solve R^T u = t column by column in ASCENDING dependency

@@ -49,6 +49,40 @@ __device__ __forceinline__ int4 nt_load(const int4 *p)
 #endif
 constexpr int kRC = 16, kSub = 4, kTS = kRC + 1;      // columns per round, lanes per column, tile row stride (doubles)
 
+// The epilogue of a column used to be sqrt(), four divisions and a log() from the device library: ~190 of the ~375 VALU
+// instructions a column costs in the wide levels, which run at 75 % VALU busy (tools/pmc_post.sh).  Now: one v_rsq_f64
+// seeded pivot with its reciprocal, products with a residual correction instead of divisions, one reciprocal of the nugget,
+// and the logarithm left to the reduction kernel that sums it (R_kk is stored instead of log R_kk).
+// r = sqrt(x) and 1/r from one v_rsq_f64 seed (Goldschmidt), x > 0 finite; x <= 0 or NaN gives NaN like sqrt()
+__device__ __forceinline__ void top_pivot(const double x, double &r, double &rinv)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, e, g);
+    h = __builtin_fma(h, e, h);
+    r = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    const double w = h + h;
+    rinv = __builtin_fma(w, __builtin_fma(-r, w, 1.0), w);
+}
+// a / r given rinv ~ 1/r: product plus one residual correction
+__device__ __forceinline__ double top_div(const double a, const double r, const double rinv)
+{
+    const double q = a * rinv;
+    return __builtin_fma(__builtin_fma(-q, r, a), rinv, q);
+}
+// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps; x = Inf -> 0 (an unobserved point's nugget, R/vecchia_laplace_NR.R:107-108)
+// and x = 0 -> Inf survive (the Newton residual is NaN there and the raw result is kept)
+__device__ __forceinline__ double post_rcp(const double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r0, 1.0);
+    double r = __builtin_fma(r0, e, r0);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return (r == r) ? r : r0;
+}
+
 // One column of the factor.  c0, c1: its column record.
 // MODE 1 (the columns of the dense top block, gpv_posterior_top_kernel): no epilogue, the partial sums (64 rows, z2, s) go to
 // tpart; the first entries of the row list, up to c1.y, are the other top columns, whose R and t do not exist yet: their
@@ -169,15 +203,17 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         return;
     }
     if (lane < cnt) acc = __builtin_fma(bk_own, dk, acc);             // c == k term: B_ik d_k
-    const double accd = __shfl(acc, cnt - 1, 64) + 1.0 / tau;
-    const double rkk = sqrt(accd);
-    if (lane < cnt) Ck[1 + lane].y = (lane == cnt - 1) ? rkk : acc / rkk;
+    const double itau = post_rcp(tau);
+    const double accd = __shfl(acc, cnt - 1, 64) + itau;
+    double rkk, rinv;
+    top_pivot(accd, rkk, rinv);
+    if (lane < cnt) Ck[1 + lane].y = (lane == cnt - 1) ? rkk : top_div(acc, rkk, rinv);
     if (lane == 0) {
-        z2 -= zk / tau;                              // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
-        const double t = (z2 - s) / rkk;
+        z2 = __builtin_fma(-zk, itau, z2);           // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
+        const double t = top_div(z2 - s, rkk, rinv);
         Ck[0].y = t;
         A.tvec[k] = t;
-        A.logr[k] = log(rkk);
+        A.rdiag[k] = rkk;
     }
 }
 
@@ -201,21 +237,22 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
 // C <- (B, 0) from the row-major Lentries, heads <- (a, 0): one thread per compact entry, coalesced writes
 __global__ void __launch_bounds__(256) gpv_posterior_compact_kernel(const double *L, int ld, const double *avec,
                                                                     const int32_t *colptr, const int32_t *ccol,
-                                                                    const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C)
+                                                                    const uint8_t *cslot, const int32_t *cdel, int64_t n,
+                                                                    int64_t nnz, double2 *C)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nnz; g += stride) {
         const int c = ccol[g];
-        C[g + c + 1] = make_double2(L[(int64_t)c * ld + cslot[g]], 0.0);
+        C[g + cdel[c] + 1] = make_double2(L[(int64_t)c * ld + cslot[g]], 0.0);
     }
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride)
-        C[(int64_t)colptr[c] + c] = make_double2(avec[c], 0.0);
+        C[(int64_t)colptr[c] + cdel[c]] = make_double2(avec[c], 0.0);
 }
 hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
-                                    const uint8_t *cslot, int64_t n, int64_t nnz, double2 *C, hipStream_t s)
+                                    const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gpv_posterior_compact_kernel, dim3(4096), dim3(256), 0, s, L, ld, avec, colptr, ccol, cslot, n, nnz, C);
+    hipLaunchKernelGGL(gpv_posterior_compact_kernel, dim3(4096), dim3(256), 0, s, L, ld, avec, colptr, ccol, cslot, cdel, n, nnz, C);
     return hipGetLastError();
 }
 
@@ -231,14 +268,16 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
     double2 *Ck = A.C + c0.y;
     const double dk = Ck[cnt].x;
     const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
-    const double rkk = sqrt(__builtin_fma(dk, dk, 0.0) + 1.0 / tau);
-    for (int e = sub; e < cnt; e += 16) Ck[1 + e].y = (e == cnt - 1) ? rkk : __builtin_fma(Ck[1 + e].x, dk, 0.0) / rkk;
+    const double itau = post_rcp(tau);
+    double rkk, rinv;
+    top_pivot(__builtin_fma(dk, dk, 0.0) + itau, rkk, rinv);
+    for (int e = sub; e < cnt; e += 16) Ck[1 + e].y = (e == cnt - 1) ? rkk : top_div(__builtin_fma(Ck[1 + e].x, dk, 0.0), rkk, rinv);
     if (sub == 0) {
-        const double z2 = __builtin_fma(dk, Ck[0].x, 0.0) - A.z[k] / tau;
-        const double t = (z2 - 0.0) / rkk;
+        const double z2 = __builtin_fma(-A.z[k], itau, __builtin_fma(dk, Ck[0].x, 0.0));
+        const double t = top_div(z2 - 0.0, rkk, rinv);
         Ck[0].y = t;
         A.tvec[k] = t;
-        A.logr[k] = log(rkk);
+        A.rdiag[k] = rkk;
     }
 }
 
@@ -260,24 +299,6 @@ __device__ __forceinline__ double readlane_f64(double v, int l)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(v), l);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double((int)hi, (int)lo);
-}
-// pivot of the top block: r = sqrt(x) and 1/r from one v_rsq_f64 seed (Goldschmidt), x > 0; x <= 0 or NaN gives NaN like sqrt()
-__device__ __forceinline__ void top_pivot(const double x, double &r, double &rinv)
-{
-    const double y = __builtin_amdgcn_rsq(x);
-    double g = x * y, h = 0.5 * y;
-    const double e = __builtin_fma(-h, g, 0.5);
-    g = __builtin_fma(g, e, g);
-    h = __builtin_fma(h, e, h);
-    r = __builtin_fma(__builtin_fma(-g, g, x), h, g);
-    const double w = h + h;
-    rinv = __builtin_fma(w, __builtin_fma(-r, w, 1.0), w);
-}
-// a / r given rinv ~ 1/r: product plus one residual correction
-__device__ __forceinline__ double top_div(const double a, const double r, const double rinv)
-{
-    const double q = a * rinv;
-    return __builtin_fma(__builtin_fma(-q, r, a), rinv, q);
 }
 // Step C of the factorisation.  On entry column C of R is final: Rc in this lane's register and, for all rows, in Rb.  The
 // pivot column of the NEXT step is updated first, then the other C-1 columns.  (Interleaving the next pivot's serial chain
@@ -331,19 +352,20 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
     if (wave == 0) { zl[lane] = 0.0; sl[lane] = 0.0; }
     __syncthreads();
     // wave w loads the columns w, w + 4, ..: lane = entry of the column.  Loads first, all of them in flight together
-    int cpj[kTopJ], cntj[kTopJ], rowi[kTopJ];
+    int cpj[kTopJ], cntj[kTopJ], rowi[kTopJ], cbj[kTopJ];
 #pragma unroll
     for (int j = 0; j < kTopJ; ++j) {
         const int k = wave + kTopWaves * j;
         cpj[j] = (k < K) ? A.colptr[k] : 0;
         cntj[j] = (k < K) ? A.colptr[k + 1] - cpj[j] : 0;
+        cbj[j] = (k < K) ? A.cboff[k] : 0;
     }
     double vb[kTopJ], vd[kTopJ], vp[kTopJ], vt[kTopJ], vz[kTopJ], vpz[kTopJ], vps[kTopJ];
 #pragma unroll
     for (int j = 0; j < kTopJ; ++j) {
         const int k = wave + kTopWaves * j;
         const bool own = lane < cntj[j];
-        const double2 *Ck = A.C + (int64_t)cpj[j] + k;
+        const double2 *Ck = A.C + cbj[j];
         rowi[j] = own ? A.crow[cpj[j] + lane] : -1;
         vb[j] = own ? Ck[1 + lane].x : 0.0;
         vd[j] = own ? Ck[cntj[j]].x : 0.0;
@@ -401,13 +423,13 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
     for (int j = 0; j < kTopJ; ++j) {
         const int k = wave + kTopWaves * j;
         if (k < K) {
-            double2 *Ck = A.C + (int64_t)cpj[j] + k;
+            double2 *Ck = A.C + cbj[j];
             if (rowi[j] >= 0) Ck[1 + lane].y = Sl[rowi[j]][k];
             if (lane == 0) {
                 const double t = tl[k];
                 Ck[0].y = t;
                 A.tvec[k] = t;
-                A.logr[k] = log(rl[k]);
+                A.rdiag[k] = rl[k];
             }
         }
     }
@@ -483,7 +505,7 @@ __global__ void __launch_bounds__(256) gpv_mean_level_kernel(const PostArgs A, c
     double part = 0.0, rkk = 1.0;
     if (lane < cnt) {
         const int i = A.crow[cp + lane];
-        const double r = A.C[(int64_t)cp + k + 1 + lane].y;
+        const double r = A.C[(int64_t)A.cboff[k] + 1 + lane].y;
         if (lane == cnt - 1) rkk = r; else part = r * u[i];
     }
 #pragma unroll
@@ -515,7 +537,7 @@ __global__ void __launch_bounds__(1024) gpv_mean_head_kernel(const PostArgs A, c
             double part = 0.0, rkk = 1.0;
             if (lane < cnt) {
                 const int i = A.crow[cp + lane];
-                const double r = A.C[(int64_t)cp + k + 1 + lane].y;
+                const double r = A.C[(int64_t)A.cboff[k] + 1 + lane].y;
                 if (lane == cnt - 1) rkk = r;
                 else part = r * __hip_atomic_load(&u[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -546,13 +568,13 @@ hipError_t launch_negate(const double *src, double *dst, int64_t n, hipStream_t 
     return hipGetLastError();
 }
 
-// ---- deterministic pair reduction: out[0] = sum x, out[1] = sum y^2 ------------------------------------
+// ---- deterministic pair reduction: out[0] = sum log x, out[1] = sum y^2 --------------------------------
 __global__ void __launch_bounds__(256) gpv_sum_pair_stage1(const double *x, const double *y, int64_t n, double *partials)
 {
     __shared__ double sx[256], sy[256];
     double ax = 0.0, ay = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        ax += x[i];
+        ax += log(x[i]);
         ay = __builtin_fma(y[i], y[i], ay);
     }
     sx[threadIdx.x] = ax;
