@@ -312,14 +312,11 @@ __device__ __forceinline__ lds_wdouble *lds_wptr(unsigned a) { return (lds_wdoub
 // scale * exp(-t) for the closed-form Matern families, two instructions shorter per value than scale * exp_neg(t):
 //   * the Horner coefficients are multiplied by scale (= sigma^2) once per wavefront and kept in SGPRs, so the value
 //     leaves the polynomial already scaled;
-//   * k = round(-t log2 e) is taken from the low mantissa bits of -t log2 e + 1.5 * 2^52 and added straight into the
-//     exponent field of the result (no v_cvt_i32_f64, no v_ldexp_f64).  t is clamped so that the result stays a normal
-//     number (tmax: 700, less what a scale below 1 takes from the exponent range); past the clamp the value is
-//     scale * e^-tmax ~ 2^-1010 instead of something smaller: below 2^-65 of the block's diagonal (>= scale) for any
-//     scale >= 2^-945 ~ 1e-284, i.e. invisible in FP64 (tests: sigma^2 from 1e-200 to 1e200).
+//   * k = round(-t log2 e) is read as an integer from the low mantissa bits of -t log2 e + 1.5 * 2^52 (no v_rndne_f64 +
+//     v_cvt_i32_f64 pair) and goes straight into v_ldexp_f64, which also takes care of gradual underflow: exp(-t)
+//     is exactly 0 beyond t ~ 745 like the reference's exp() (t is clamped at 1000 only to keep k in range).
 struct ExpScaled {
     double c[12];                                   // scale * (c11 .. c2), then scale, scale
-    double tmax;
 };
 __device__ __forceinline__ double sgpr_f64(double x)
 {
@@ -336,14 +333,11 @@ __device__ __forceinline__ ExpScaled exp_scaled_setup(const double scale)
 #pragma unroll
     for (int i = 0; i < 10; ++i) E.c[i] = sgpr_f64(k[i] * scale);
     E.c[10] = E.c[11] = sgpr_f64(scale);
-    const int es = __builtin_amdgcn_frexp_exp(scale);                       // scale = m 2^es, m in [0.5, 1)
-    const double room = (double)(1010 + (es < 0 ? es : 0)) * 0.6931471805599453;
-    E.tmax = sgpr_f64(__builtin_fmin(__builtin_fmax(room, 0.0), 700.0));
     return E;
 }
 __device__ __forceinline__ double exp_neg_scaled(double t, const ExpScaled &E)
 {
-    t = __builtin_fmin(t, E.tmax);
+    t = __builtin_fmin(t, 1000.0);
     const double kk = __builtin_fma(t, -1.4426950408889634, 0x1.8p52);
     const double kd = kk - 0x1.8p52;
     double r = __builtin_fma(kd, -6.93147180369123816490e-01, -t);
@@ -351,8 +345,7 @@ __device__ __forceinline__ double exp_neg_scaled(double t, const ExpScaled &E)
     double p = fma_vvs(E.c[0], r, E.c[1]);
 #pragma unroll
     for (int i = 2; i < 12; ++i) p = fma_vvs(p, r, E.c[i]);
-    const int hi = __double2hiint(p) + (__double2loint(kk) << 20);
-    return __hiloint2double(hi, __double2loint(p));
+    return __builtin_ldexp(p, __double2loint(kk));
 }
 
 // Running sum of logarithms without a log per term: log(x_1 ... x_T) = log(prod) + esum ln 2 with the product kept in

@@ -16,7 +16,10 @@ def _need_gpu():
     return G
 
 
-@pytest.mark.parametrize("seed", range(24))
+# 62, 76, 86: one-dimensional exponential covariances (found by a 200-seed sweep): a Markov process, the weights of all
+# but the adjacent neighbours are exactly zero in exact arithmetic, and the oracle's elimination order happens to return
+# 0.0 where another order returns 1e-17 of the row's largest entry
+@pytest.mark.parametrize("seed", list(range(24)) + [62, 76, 86])
 def test_random_shapes_against_oracle(seed):
     G = _need_gpu()
     from oracle import r_side as R
@@ -47,7 +50,12 @@ def test_random_shapes_against_oracle(seed):
     out = G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], tau, tau, covmodel, cp)
     assert out["n_failed"] == ref["U_entries"]["n_failed"]
     L0, L1 = ref["U_entries"]["Lentries"], out["Lentries"]
-    np.testing.assert_array_equal(L1 == 0, L0 == 0)
+    # same zero pattern (padding, failed rows) — except where a value that is zero in exact arithmetic comes out as an
+    # exact 0.0 on one side and as rounding noise on the other
+    rowmax = np.maximum(np.abs(L0).max(axis=1, keepdims=True), 1e-300)
+    differs = (L1 == 0) != (L0 == 0)
+    assert not np.any(differs & (np.maximum(np.abs(L0), np.abs(L1)) > 1e-13 * rowmax))
+    np.testing.assert_array_equal((L1 == 0).all(axis=1), (L0 == 0).all(axis=1))          # failed rows stay all-zero
     covfun = R.EsqeFun if covmodel == "esqe" else R.MaternFun
     eps = np.finfo(float).eps
     for k in range(n):

@@ -1,0 +1,16 @@
+"""Developer tool: the random-shape parity test of tests/test_gpu_fuzz.py over many more seeds (one-off sweeps on a GPU box).
+
+    python tools/fuzz_more.py
+"""
+import sys, os, traceback
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import torch  # noqa
+import test_gpu_fuzz as F
+bad = 0
+for seed in range(24, 424):
+    try:
+        F.test_random_shapes_against_oracle.__wrapped__(seed) if hasattr(F.test_random_shapes_against_oracle, "__wrapped__") else F.test_random_shapes_against_oracle(seed)
+    except Exception as e:
+        bad += 1
+        print("SEED", seed, "FAILED:", repr(e)[:300])
+print("extended fuzz done, failures:", bad)
