@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+(time python bench.py) 2>&1 | tail -5 | cut -c1-600
