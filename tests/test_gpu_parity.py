@@ -720,6 +720,41 @@ def test_dense_top_block_of_posterior_pass_matches_level_schedule():
     assert res["1"]["40"]["levels"] == 0 and res["1"]["64"]["levels"] == 0 and res["1"]["65"]["levels"] == 1
 
 
+def test_plans_release_their_device_memory():
+    # create / evaluate / destroy in a loop (likelihood, posterior pass with mean, Vecchia-Laplace state, general-nu table,
+    # literal drop-in with its plan cache): the free device memory must come back to where it started
+    G = _need_gpu()
+    import gc
+    import torch
+    from gpvecchia_amd import _lib as L
+    rng = np.random.default_rng(1)
+    n, m = 20_000, 20
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+
+    def cycle():
+        va = G.vecchia_specify(locs, m, cond_yz="SGV")
+        G.vecchia_likelihood(z, va, [1.0, 0.05, 1.5], 0.1)
+        G.vecchia_likelihood(z, va, [1.0, 0.05, 1.1], 0.1)                 # general nu: table buffers
+        G.vecchia_prediction(z, va, [1.0, 0.05, 1.5], 0.1)                 # mean sweep buffers
+        G.calculate_posterior_VL(rng.poisson(1.0, n).astype(float), va, "poisson", [1.0, 0.05, 1.5])
+        prep = va["U_prep"]
+        G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], np.full(n, .1), np.full(n, .1), "matern",
+                      [1.0, 0.05, 1.5])
+        del va
+        gc.collect()
+
+    cycle()                                                                # first use: runtime / RCCL-free one-time allocations
+    L.lib().gpv_plan_cache_clear()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        cycle()
+    L.lib().gpv_plan_cache_clear()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, f"device memory not returned: {(free0 - free1) / 2**20:.1f} MiB after 6 cycles"
+
+
 @pytest.mark.parametrize("cond", ["SGV", "z"])
 def test_likelihood_reuses_resident_data_only_when_it_is_the_same(cond):
     # vecchia_likelihood keeps the data vector on the device between calls (an optimiser passes the same z every time); the
