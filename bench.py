@@ -138,12 +138,30 @@ def kernel_code_sha256():
     return hashlib.sha256("".join(src.split()).encode()).hexdigest()
 
 
+def count_gpus_sysfs():
+    """GPUs of this box counted from the KFD topology in sysfs (nodes with simd_count > 0), honouring the
+    HIP/ROCR_VISIBLE_DEVICES lists: the launching parent never opens the driver, not even to count devices."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args):
-    """--gpus N > 1 without a launcher: start the N ranks as fresh processes.  Nothing in this process has touched
-    the GPU (torch.cuda.device_count() does not initialise it), and nothing is exec'ed."""
-    import torch
+    """--gpus N > 1 without a launcher: start the N ranks as fresh processes.  Nothing in this process touches the GPU
+    or the driver (the GPUs are counted in sysfs), and nothing is exec'ed."""
     backend = os.environ.get("GPV_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
+    ndev = count_gpus_sysfs()
     if backend == "nccl" and ndev < args.gpus:
         print(f"[bench] --gpus {args.gpus} but only {ndev} GPU(s) visible: refusing to report a {args.gpus}-GPU number",
               file=sys.stderr)
@@ -154,6 +172,115 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     return subprocess.run(cmd, env=env).returncode
+
+
+def other_config(name, device, measure_with, steps=10):
+    """BASELINE.json configs[1] / configs[3] on one GPU, mode L: evals/s, set-kernel ms, FP64 fraction."""
+    import gpvecchia_amd as G
+    ci, n, m, d, nu, rng_ = CONFIGS[name]
+    t0 = time.time()
+    locs, z, revNN, revCond, a, b = build_workload(n, m, d, 0, 1, device=device)
+    plan = G.Plan(locs, revNN, revCond, device=device)
+    plan.set_data(z)
+    ts = time.time() - t0
+    cp = [1.0, rng_, nu]
+    el, km, ll = measure_with(plan, G.GPV_WANT_LOGLIK_Z, False, steps, 2, cp, 0.1, n)
+    tf = flops_per_set(m + 1, d) * n / (km * 1e-3) / 1e12
+    del plan
+    return {"value": steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / steps, "kernel_ms": km,
+            "kernel": f"gpv_sets_kernel<{m + 1},{d}>", "fp64_frac": tf / FP64_PEAK_TF, "fp64_tflops": tf, "loglik": ll,
+            "setup_s": round(ts, 2),
+            "what": f"BASELINE.json configs[{ci}]: n={n} {d}-D, m={m}, Matern nu={nu}, range {rng_}, cond.yz='z', mode L, 1 GPU"}
+
+
+def vl_config(device, n=500_000, m=30):
+    """BASELINE.json configs[4]: Vecchia-Laplace, Poisson data, maxmin + SGV, one GPU (the posterior pass does not shard)."""
+    import gpvecchia_amd as G
+    rng = np.random.default_rng(0)
+    locs = rng.random((n, 2))
+    y = 0.8 * np.sin(5 * locs[:, 0]) * np.cos(4 * locs[:, 1]) + 0.3       # a cheap smooth latent field (SURVEY.md §8d, C5)
+    z = rng.poisson(np.exp(y)).astype(float)
+    cp = [1.0, 0.03, 1.5]
+    t0 = time.time()
+    va = G.vecchia_specify(locs, m, nn_backend="gpu")                      # defaults: maxmin, SGV
+    t_spec = time.time() - t0
+    t0 = time.time()
+    post = G.calculate_posterior_VL(z, va, "poisson", cp, device=device)   # includes plan upload + posterior structure
+    t_first = time.time() - t0
+    t_nr = []
+    for _ in range(3):
+        t0 = time.time()
+        post = G.calculate_posterior_VL(z, va, "poisson", cp, device=device)
+        t_nr.append(time.time() - t0)
+    t_nr = float(np.median(t_nr))
+    t_ll = []
+    for _ in range(3):
+        t0 = time.time()
+        ll = G.vecchia_laplace_likelihood(z, va, "poisson", cp, device=device)
+        t_ll.append(time.time() - t0)
+    return {"ms_per_nr_iter": 1e3 * t_nr / max(post["iter"], 1), "nr_iters": int(post["iter"]), "converged": bool(post["cnvgd"]),
+            "nr_loop_s": t_nr, "vecchia_laplace_likelihood_s": float(np.median(t_ll)), "loglik": ll,
+            "rmse_latent": float(np.sqrt(np.mean((post["mean"] - y) ** 2))), "specify_s": round(t_spec, 2),
+            "first_call_s": round(t_first, 2),
+            "what": f"BASELINE.json configs[4]: n={n} 2-D, Poisson, m={m}, ordering='maxmin', cond.yz='SGV'; whole "
+                    "calculate_posterior_VL call divided by its Newton steps; 1 GPU (replicas only at N > 1)"}
+
+
+def dropin_config(n, locs, revNN, revCond, covparms, tau):
+    """SURVEY.md §8d mode U+D2H: the literal drop-in gpv_U_NZentries with host buffers in, Lentries/Zentries to host buffers
+    out (PCIe inclusive).  The first call builds and caches the device plan; the timed calls are what createU pays per
+    optimiser step."""
+    import gpvecchia_amd as G
+    from gpvecchia_amd import _lib as L
+    lf = np.asfortranarray(locs)
+    nn = np.asfortranarray(revNN.astype(np.int32))
+    cd = np.asfortranarray(np.where(revCond < 0, L.NA_INTEGER, revCond).astype(np.int32))
+    nug = np.full(n, tau)
+    cp = np.ascontiguousarray(covparms, dtype=np.float64)
+    p = nn.shape[1]
+    Lent = np.empty((n, p), order="F")
+    Z = np.empty(2 * n)
+    import ctypes as C
+    ci = lambda v: C.byref(C.c_int(int(v)))
+    nfail, status, ct = C.c_int(0), C.c_int(0), C.c_char_p(b"matern")
+    t = []
+    for it in range(5):                               # the C symbol itself, as R's .C() would call it (INTEGRATION.md)
+        t0 = time.perf_counter()
+        L.lib().gpv_U_NZentries(ci(1), ci(n), ci(n), ci(lf.shape[1]), ci(p), L.dptr(lf), L.iptr(nn), L.iptr(cd), L.dptr(nug),
+                                L.dptr(nug), C.byref(ct), L.dptr(cp), ci(cp.size), L.dptr(Lent), L.dptr(Z), C.byref(nfail),
+                                C.byref(status))
+        t.append(time.perf_counter() - t0)
+        L.check(status.value, "gpv_U_NZentries")
+    dk_ok = bool(np.all(Lent[np.arange(0, n, 9973), (nn[::9973] != 0).sum(axis=1) - 1] > 0))
+    L.lib().gpv_plan_cache_clear()
+    return {"first_call_ms": 1e3 * t[0], "ms_per_call": 1e3 * float(np.median(t[1:])), "n_failed": int(nfail.value),
+            "diag_positive_on_sample": dk_ok, "bytes_to_host": int(8 * n * p + 16 * n),
+            "what": "mode U+D2H: the C symbol gpv_U_NZentries at C3 with host buffers in and out (caller-allocated outputs), plan "
+                    "cached from the first call; includes content hash, nuggets H2D, kernel, transpose and the D2H copy"}
+
+
+def per_rank_step(args, emulate=8, steps=200):
+    """What ONE rank pays per step at the per-rank load of an `emulate`-GPU run: rows = n / emulate on this GPU, through the
+    RCCL path (a child started with torch.distributed.run, world 1, backend nccl).  Emulated load, NOT a scaling number:
+    a real all-reduce adds its xGMI round."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "20",
+           "--emulate-world", str(emulate), "--no-cpu-baseline", "--no-secondary", "--config", args.config]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not line:
+        raise RuntimeError(f"child failed ({r.returncode}): {r.stderr[-600:]}")
+    j = json.loads(line[-1])
+    k_ms = j["roofline"]["kernel_ms"]
+    return {"ms_per_step": j["ms_per_step"], "kernel_ms": k_ms, "overhead_us": 1e3 * (j["ms_per_step"] - k_ms),
+            "rows": j["roofline"]["sets_per_launch"], "emulated_world": emulate, "backend": "nccl (RCCL), world 1",
+            "what": "emulated per-rank load, not a scaling number: one GPU takes rank 0's shard of an 8-rank job and runs the "
+                    "step of the N > 1 path (kernel with fused reduction, RCCL all_reduce of 8 doubles, pinned copy, polled "
+                    "event); overhead_us = ms_per_step - kernel_ms is the fixed cost strong scaling pays per step"}
 
 
 def main():
@@ -176,6 +303,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the mode U / mode S secondary measurements")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0,
                     help="per-repeat wall budget of the CPU baseline; the whole data set is timed when it fits")
+    ap.add_argument("--emulate-world", type=int, default=1,
+                    help="developer/secondary measurement: this rank takes the row shard rank 0 of a job of that many ranks "
+                         "would own (rows = n / E) while the collectives run over the real world; NOT a scaling number")
     ap.add_argument("--self-check", action="store_true",
                     help="N > 1: rank 0 also evaluates the unsharded plan and asserts the N-rank log-likelihood equals it to 1e-12")
     args = ap.parse_args()
@@ -245,6 +375,7 @@ def main():
     assert stream != 0
     sums = torch.zeros(G._lib.NSUMS, dtype=torch.float64, device="cuda")
     pinned = torch.zeros(G._lib.NSUMS, dtype=torch.float64).pin_memory()
+    done = torch.cuda.Event()
 
     def fence():
         torch.cuda.synchronize()
@@ -253,6 +384,9 @@ def main():
         torch.cuda.synchronize()
 
     def measure(plan, flags, denom, steps, warmup):
+        return measure_with(plan, flags, denom, steps, warmup, covparms, tau, n)
+
+    def measure_with(plan, flags, denom, steps, warmup, covparms, tau, n):
         """W untimed + K timed evaluations of `plan`; returns (seconds, mean set-kernel ms, loglik)."""
         def step():
             plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
@@ -261,7 +395,9 @@ def main():
             # the 8 sums reach the host every step through a pinned buffer: copy on the launch stream, then wait for
             # that stream only
             pinned.copy_(sums, non_blocking=True)
-            tstream.synchronize()
+            done.record(tstream)
+            while not done.query():                               # spin on the event's flag: no interrupt-driven wake-up
+                pass
             host = pinned.numpy()
             return G.loglik_from_sums(host, n) if denom else G.loglik_z_from_sums(host, n)
         ll = None
@@ -272,17 +408,18 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             ll = step()
-            kms.append(plan.last_kernel_ms())                    # hipEvent pair on the launch stream, already complete
+            if plan.kernel_timing:
+                kms.append(plan.last_kernel_ms())                # hipEvent pair on the launch stream, already complete
         fence()
         el = time.perf_counter() - t0
-        return el, float(np.mean(kms)), ll
+        return el, (float(np.mean(kms)) if kms else float("nan")), ll
 
     def roofline(k_ms, rows_rank, mode, traffic=None):
         ab = alg_bytes_per_set(p, d, mode) * rows_rank
         gbs = ab / (k_ms * 1e-3) / 1e9
         tf = flops_per_set(p, d) * rows_rank / (k_ms * 1e-3) / 1e12
         return {"bound": "fp64_valu", "achieved": tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TF,
-                "traffic": traffic, "kernel": f"gpv_sets_kernel<{p},{d}>", "kernel_ms": k_ms,
+                "traffic": traffic, "kernel": f"gpv_sets_kernel<{p},{d}>", "kernel_ms": k_ms, "kernel_ms_from": timing_note,
                 "flops_per_set": flops_per_set(p, d), "sets_per_launch": rows_rank,
                 "note": "binding roofline is FP64 VALU issue, not HBM or MFMA (blocks are (m+1)x(m+1); DESIGN.md §4); "
                         "flop model of SURVEY.md §8d",
@@ -301,13 +438,28 @@ def main():
         a, b = 0, n
         flags, denom = G.GPV_WANT_DENOM, True
     else:
-        locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, device=local_rank)
+        if args.emulate_world > 1:
+            if world != 1:
+                raise SystemExit("--emulate-world is a one-rank measurement")
+            locs, z, revNN, revCond, a, b = build_workload(n, m, d, 0, args.emulate_world, device=local_rank)
+        else:
+            locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, device=local_rank)
         plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
         plan.set_data(z)
         flags, denom = G.GPV_WANT_LOGLIK_Z | (G.GPV_WANT_U if args.mode == "U" else 0), False
     t_setup = time.time() - t_setup
 
-    elapsed, k_ms, loglik = measure(plan, flags, denom, args.steps, args.warmup)
+    timing_note = "hipEvent pair around every launch of the timed region, on the launch stream"
+    if use_dist:
+        # at a fraction of a millisecond per step the event pair itself costs 7-10 us (two queue packets per launch): the K
+        # timed steps run without it, the kernel's duration comes from an instrumented repeat of the same K steps
+        plan.set_kernel_timing(False)
+        elapsed, _, loglik = measure(plan, flags, denom, args.steps, args.warmup)
+        plan.set_kernel_timing(True)
+        _, k_ms, _ = measure(plan, flags, denom, args.steps, 1)
+        timing_note = "hipEvent pair around every launch of an instrumented repeat of the K timed steps (events off while timing)"
+    else:
+        elapsed, k_ms, loglik = measure(plan, flags, denom, args.steps, args.warmup)
     if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         all_reduce_(te, dist.ReduceOp.MAX)
@@ -352,7 +504,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"n={n} {d}-D uniform, Matern nu={nu}, m={m}, ordering={ord_s}, cond.yz={cond_s}, "
                                    f"mode {args.mode} (" + ("custom sizes" if custom else f"BASELINE.json configs[{ci}]")
-                                   + f"; rows sharded over {world} GPU(s))",
+                                   + (f"; rows sharded over {world} GPU(s))" if args.emulate_world == 1 else
+                                      f"; THIS RANK'S SHARD of an emulated {args.emulate_world}-rank job only)"),
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
                        "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2)},
             "roofline": roofline(k_ms, rows_rank, args.mode, traffic),
@@ -385,6 +538,26 @@ def main():
                     del ps, va
                 except Exception as e:                       # never lose the headline line to a secondary failure
                     sec["mode_S"] = {"error": repr(e)}
+            if args.config == "C3" and not custom:
+                # the other BASELINE.json configurations and SURVEY.md §8d's third mode, each timed by this same run
+                del plan
+                for name in ("C2", "C4"):
+                    try:
+                        sec[name] = other_config(name, local_rank, measure_with)
+                    except Exception as e:
+                        sec[name] = {"error": repr(e)}
+                try:
+                    sec["C5_vl"] = vl_config(local_rank)
+                except Exception as e:
+                    sec["C5_vl"] = {"error": repr(e)}
+                try:
+                    sec["dropin_U_D2H"] = dropin_config(n, locs, revNN, revCond, covparms, tau)
+                except Exception as e:
+                    sec["dropin_U_D2H"] = {"error": repr(e)}
+                try:
+                    sec["per_rank_step"] = per_rank_step(args)
+                except Exception as e:
+                    sec["per_rank_step"] = {"error": repr(e)}
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.mode != "S":
             cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - min(b - a - 2 * p, 60000), b), repeats=2)

@@ -24,15 +24,17 @@ GPV_WANT_MEAN = 16
 
 # every symbol include/gpvecchia.h declares (tests check the library exports all of them)
 EXPORTS = [
-    "gpv_status_string", "gpv_version", "gpv_device_count", "gpv_max_p",
+    "gpv_status_string", "gpv_last_hip_error", "gpv_version", "gpv_device_count", "gpv_max_p",
     "gpv_U_NZentries", "gpv_U_NZentries_mat", "gpv_MaternFun", "gpv_EsqeFun",
     "gpv_plan_create", "gpv_plan_destroy", "gpv_plan_set_data", "gpv_plan_eval",
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
-    "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms",
+    "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms", "gpv_plan_set_kernel_timing",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
     "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
     "gpv_plan_cache_clear", "gpv_plan_cache_stats", "gpv_plan_vl_begin", "gpv_plan_vl_step", "gpv_plan_vl_get",
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
+    "gpv_mplan_create_replicas", "gpv_mplan_count", "gpv_mplan_set_data_one", "gpv_mplan_build_posterior",
+    "gpv_mplan_eval_each", "gpv_mplan_vl_begin_one", "gpv_mplan_vl_step_each", "gpv_mplan_vl_get_one",
 ]
 
 
@@ -40,6 +42,10 @@ class GpvError(RuntimeError):
     def __init__(self, status: int, where: str = ""):
         self.status = status
         msg = lib().gpv_status_string(status).decode()
+        if status == 6:                                   # GPV_ERR_HIP: say which HIP call failed and how
+            buf = C.create_string_buffer(256)
+            code = lib().gpv_last_hip_error(buf, 256)
+            msg += f" -- hipError_t {code}: {buf.value.decode(errors='replace')}"
         super().__init__(f"libgpvecchia_hip: {where}: {msg} (status {status})")
 
 
@@ -59,6 +65,8 @@ def lib():
     L.gpv_status_string.restype = C.c_char_p
     L.gpv_status_string.argtypes = [C.c_int]
     L.gpv_version.restype = C.c_int
+    L.gpv_last_hip_error.restype = C.c_int
+    L.gpv_last_hip_error.argtypes = [C.c_char_p, C.c_int]
     L.gpv_device_count.argtypes = [ip]
     L.gpv_max_p.restype = C.c_int
     L.gpv_U_NZentries.restype = None
@@ -72,13 +80,14 @@ def lib():
     L.gpv_plan_create.argtypes = [C.POINTER(vp), C.c_int, i64, C.c_int, C.c_int, dp, ip, ip, i64, i64]
     L.gpv_plan_destroy.argtypes = [vp]
     L.gpv_plan_set_data.argtypes = [vp, dp]
-    L.gpv_plan_eval.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, i64, C.c_int, vp, vp]
+    L.gpv_plan_eval.argtypes = [vp, C.c_char_p, vp, C.c_int, vp, i64, C.c_int, vp, vp]   # (data pointers as integers: cheaper marshalling)
     L.gpv_plan_get_sums.argtypes = [vp, dp]
     L.gpv_plan_get_Lentries.argtypes = [vp, dp]
     L.gpv_plan_get_Zentries.argtypes = [vp, dp]
     L.gpv_plan_Lentries_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.gpv_plan_rows.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
     L.gpv_plan_last_kernel_ms.argtypes = [vp, dp]
+    L.gpv_plan_set_kernel_timing.argtypes = [vp, C.c_int]
     L.gpv_loglik_z_from_sums.argtypes = [dp, i64, dp]
     L.gpv_numerator_from_sums.argtypes = [dp, dp, dp]
     L.gpv_plan_build_posterior.argtypes = [vp, ip, ip]
@@ -90,6 +99,14 @@ def lib():
     L.gpv_mplan_set_data.argtypes = [vp, dp]
     L.gpv_mplan_eval.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, i64, C.c_int, dp]
     L.gpv_mplan_get_Lentries.argtypes = [vp, dp]
+    L.gpv_mplan_create_replicas.argtypes = [C.POINTER(vp), ip, C.c_int, i64, C.c_int, C.c_int, dp, ip, ip]
+    L.gpv_mplan_count.argtypes = [vp, ip]
+    L.gpv_mplan_set_data_one.argtypes = [vp, C.c_int, dp]
+    L.gpv_mplan_build_posterior.argtypes = [vp, ip, ip]
+    L.gpv_mplan_eval_each.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, C.c_int, dp]
+    L.gpv_mplan_vl_begin_one.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
+    L.gpv_mplan_vl_step_each.argtypes = [vp, C.c_char_p, dp, C.c_int, ip, dp, ip]
+    L.gpv_mplan_vl_get_one.argtypes = [vp, C.c_int, dp, dp, dp]
     L.gpv_order_maxmin_exact.argtypes = [dp, i64, C.c_int, ip]
     L.gpv_ic0.argtypes = [i64, ip, ip, dp, C.POINTER(C.c_int64)]
     L.gpv_find_ordered_nn.argtypes = [C.c_int, dp, i64, C.c_int, C.c_int, i64, i64, ip]

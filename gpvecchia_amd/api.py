@@ -94,9 +94,11 @@ class Plan:
     def eval(self, covmodel, covparms, nuggets, flags, stream=None, d_sums_out=None):
         cp = np.ascontiguousarray(covparms, dtype=np.float64)
         ng = np.ascontiguousarray(np.atleast_1d(nuggets), dtype=np.float64)
-        st = L.lib().gpv_plan_eval(self._h, str(covmodel).encode(), L.dptr(cp), int(cp.size), L.dptr(ng),
-                                   int(ng.size), int(flags), C.c_void_p(stream or 0), C.c_void_p(d_sums_out or 0))
-        L.check(st, "gpv_plan_eval")
+        st = L.lib().gpv_plan_eval(self._h, covmodel.encode() if isinstance(covmodel, str) else bytes(covmodel),
+                                   cp.ctypes.data, int(cp.size), ng.ctypes.data, int(ng.size), int(flags), stream or 0,
+                                   d_sums_out or 0)
+        if st:
+            L.check(st, "gpv_plan_eval")
 
     def sums(self):
         s = np.zeros(NSUMS)
@@ -123,6 +125,12 @@ class Plan:
         out = np.zeros(self.Nlocs)
         L.check(L.lib().gpv_plan_get_posterior_mean(self._h, L.dptr(out)), "gpv_plan_get_posterior_mean")
         return out
+
+    kernel_timing = True
+
+    def set_kernel_timing(self, on):
+        L.check(L.lib().gpv_plan_set_kernel_timing(self._h, int(bool(on))), "gpv_plan_set_kernel_timing")
+        self.kernel_timing = bool(on)
 
     def last_kernel_ms(self):
         ms = C.c_double()
@@ -168,6 +176,65 @@ class MultiPlan:
         out = np.zeros((self.Nlocs, self.p), dtype=np.float64, order="F")
         L.check(L.lib().gpv_mplan_get_Lentries(self._h, L.dptr(out)), "gpv_mplan_get_Lentries")
         return out
+
+
+class ReplicaPlans:
+    """gpv_mplan in REPLICA mode: one complete plan per listed device, each evaluating its own parameter vector (or its
+    own data set), all in flight together.  This is what several GPUs mean for the parts of the path that do not shard:
+    the posterior pass of cond.yz='SGV' and every Vecchia-Laplace Newton step (BASELINE.json configs[4])."""
+
+    def __init__(self, locsord, revNNarray, revCond, devices):
+        locs = np.asfortranarray(locsord, dtype=np.float64)
+        self.Nlocs, self.dim = locs.shape
+        self._nn = L.as_r_int_matrix(revNNarray)
+        self._cd = _cond_to_r(revCond)
+        self.p = self._nn.shape[1]
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self.count = int(dev.size)
+        self._h = C.c_void_p()
+        L.check(L.lib().gpv_mplan_create_replicas(C.byref(self._h), L.iptr(dev), self.count, self.Nlocs, self.dim, self.p,
+                                                  L.dptr(locs), L.iptr(self._nn), L.iptr(self._cd)), "gpv_mplan_create_replicas")
+        self.has_posterior = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                L.lib().gpv_mplan_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def set_data(self, z_ord, replica=None):
+        z = np.ascontiguousarray(z_ord, dtype=np.float64)
+        if z.shape[0] != self.Nlocs:
+            raise ValueError("z_ord must have one entry per ordered location")
+        if replica is None:
+            L.check(L.lib().gpv_mplan_set_data(self._h, L.dptr(z)), "gpv_mplan_set_data")
+        else:
+            L.check(L.lib().gpv_mplan_set_data_one(self._h, int(replica), L.dptr(z)), "gpv_mplan_set_data_one")
+
+    def build_posterior(self):
+        L.check(L.lib().gpv_mplan_build_posterior(self._h, L.iptr(self._nn), L.iptr(self._cd)), "gpv_mplan_build_posterior")
+        self.has_posterior = True
+
+    def eval_each(self, covmodel, covparms, nuggets, flags):
+        """covparms: (count, ncovparms), nuggets: (count,) constant nugget of each replica -> sums (count, NSUMS)."""
+        cp = np.ascontiguousarray(covparms, dtype=np.float64).reshape(self.count, -1)
+        ng = np.ascontiguousarray(np.broadcast_to(np.asarray(nuggets, dtype=np.float64), (self.count,)))
+        s = np.zeros((self.count, NSUMS))
+        L.check(L.lib().gpv_mplan_eval_each(self._h, str(covmodel).encode(), L.dptr(cp), int(cp.shape[1]), L.dptr(ng),
+                                            int(flags), L.dptr(s)), "gpv_mplan_eval_each")
+        return s
+
+    def logliks(self, covmodel, covparms, nuggets, cond_yz="SGV"):
+        """vecchia_likelihood of every replica's parameter vector: cond.yz='z' fused, 'SGV' with the posterior pass."""
+        if cond_yz == "z":
+            s = self.eval_each(covmodel, covparms, nuggets, GPV_WANT_LOGLIK_Z)
+            return np.array([loglik_z_from_sums(r, self.Nlocs) for r in s])
+        if not self.has_posterior:
+            self.build_posterior()
+        s = self.eval_each(covmodel, covparms, nuggets, GPV_WANT_DENOM)
+        return np.array([loglik_from_sums(r, self.Nlocs) for r in s])
 
 
 def _cond_to_r(revCond):

@@ -31,6 +31,9 @@ def plist():
     return [int(x) for x in re.findall(r"X\((\d+)\)", line)]
 
 
+PLIST_ONLY = None          # tuning builds: compile these row lengths only
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -49,7 +52,7 @@ def _compile(args):
 
 
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False, tag: str = "",
-          extra_flags: list[str] | None = None) -> str:
+          extra_flags: list[str] | None = None, only: list[int] | None = None) -> str:
     """tag/extra_flags build a tuning variant (libgpvecchia_hip<tag>.so, objects under build<tag>/);
     the default (no tag) is the product library."""
     global BUILD, LIB
@@ -57,14 +60,18 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
         BUILD = os.path.join(CSRC, "build" + tag)
         LIB = os.path.join(HERE, f"libgpvecchia_hip{tag}.so")
     extra_flags = list(extra_flags or [])
+    if only:
+        if not tag:
+            raise ValueError("a shortened row-length list is for tagged tuning builds only")
+        extra_flags.append("-DGPV_P_LIST(X)=" + " ".join(f"X({p})" for p in sorted(only)))
     os.makedirs(BUILD, exist_ok=True)
     H = lambda *names: [os.path.join(CSRC, f) for f in names]
     pub = os.path.join(os.path.dirname(HERE), "include", "gpvecchia.h")
     internal = H("gpv_internal.h", "gpv_bessel.hpp")
-    kern = internal + H("gpv_sets_kernel.hpp")                       # what the conditioning-set kernel TUs include
+    kern = internal + H("gpv_sets_kernel.hpp", "gpv_reduce_tail.hpp", "gpv_plist.h")   # what the conditioning-set kernel TUs include
     work = []
     inst = os.path.join(CSRC, "gpv_sets_inst.hip")
-    for P in sorted(plist(), reverse=True):          # longest compiles first
+    for P in sorted(only or plist(), reverse=True):          # longest compiles first
         if P >= SPLIT_FROM_P:                        # one TU per spatial dimension + the function that picks among them
             for d in (3, 2, 1, 0):
                 work.append((inst, os.path.join(BUILD, f"sets_p{P}_d{d}.o"),
@@ -105,5 +112,7 @@ if __name__ == "__main__":
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--tag", default="")
     ap.add_argument("--flags", default="", help="extra hipcc flags for the kernel TUs, space separated")
+    ap.add_argument("--plist", default="", help="tagged builds: compile these row lengths only, e.g. 21,31,61")
     a = ap.parse_args()
-    print(build(a.force, a.jobs, verbose=True, tag=a.tag, extra_flags=a.flags.split()))
+    print(build(a.force, a.jobs, verbose=True, tag=a.tag, extra_flags=a.flags.split(),
+                only=[int(x) for x in a.plist.split(",") if x] or None))

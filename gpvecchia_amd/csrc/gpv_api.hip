@@ -8,6 +8,7 @@
 #include "gpv_generic.h"
 #include "gpv_posterior_ext.h"
 
+#include <cstdio>
 #include <chrono>
 #include <climits>
 #include <cstdio>
@@ -22,11 +23,27 @@
 
 using namespace gpv;
 
-#define GPV_HIP(expr)                         \
-    do {                                      \
-        hipError_t e_ = (expr);               \
-        if (e_ != hipSuccess) return GPV_ERR_HIP; \
+// Every HIP failure is remembered (per host thread) with the call that produced it, so that a caller that gets
+// GPV_ERR_HIP can tell out-of-memory from a bad stream from a failed launch: gpv_last_hip_error().
+namespace {
+thread_local int g_hip_code = 0;
+thread_local char g_hip_text[256] = "";
+inline int note_hip(hipError_t e, const char *what, int line)
+{
+    g_hip_code = (int)e;
+    (void)hipGetLastError();          // HIP keeps a failure until it is read: the launch wrappers' hipGetLastError() would report it again
+    std::snprintf(g_hip_text, sizeof(g_hip_text), "%s: %s [%s, gpv_api.hip:%d]", hipGetErrorName(e), hipGetErrorString(e),
+                  what, line);
+    return GPV_ERR_HIP;
+}
+}  // namespace
+#define GPV_HIP(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) return note_hip(e_, #expr, __LINE__);     \
     } while (0)
+// the same for code that cleans up before it returns: evaluates to true on failure
+#define GPV_HIP_FAILED(expr) ([&]() { hipError_t e_ = (expr); if (e_ != hipSuccess) { note_hip(e_, #expr, __LINE__); return true; } return false; }())
 
 namespace {
 
@@ -64,6 +81,10 @@ int cov_setup(const char *covType, const double *cp, int ncov, CovSetup &c)
         } else {
             return GPV_ERR_UNSUPPORTED_NU;
         }
+        // a NaN variance or range makes every covariance NaN in the reference, every block fails and the rows stay zero
+        // (src/U_NZentries.cpp:64-66).  The kernels clamp the exponent's argument with v_min_f64, which drops a NaN, so the
+        // NaN is planted where nothing can drop it: on the diagonal of every block.
+        if (!(cp[0] == cp[0]) || !(cp[1] == cp[1])) c.sig0 = NAN;
         return GPV_OK;
     }
     if (std::strcmp(covType, "esqe") == 0) {
@@ -74,6 +95,7 @@ int cov_setup(const char *covType, const double *cp, int ncov, CovSetup &c)
         c.cA = 1.0 / cp[1];
         c.sB = cp[2];
         c.cB = 1.0 / (cp[3] * cp[3]);
+        if (!(cp[1] == cp[1]) || !(cp[3] == cp[3])) c.sig0 = NAN;     // as above (sigma1^2 / sigma2^2 NaN: sig0 is NaN already)
         return GPV_OK;
     }
     return GPV_ERR_COVTYPE;
@@ -227,6 +249,11 @@ struct gpv_plan {
            *d_block = nullptr, *d_sums = nullptr, *d_Z = nullptr, *d_tmp = nullptr, *d_covvals = nullptr,
            *d_stage = nullptr;
     int32_t *d_nn = nullptr, *d_newpos = nullptr, *d_rowid = nullptr;
+    unsigned *d_ticket = nullptr;                    // arrival counter of the set kernel's workgroups (gpv_reduce_tail.hpp)
+    // pinned host mirror of the totals: when the caller names no device mirror, the kernels write the totals straight into
+    // host memory and gpv_plan_get_sums needs no copy command, only the stream's completion
+    double *h_sums = nullptr, *h_sums_dev = nullptr;
+    bool sums_on_host = false;
     // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
     bool have_post = false;
     int32_t *d_colptr = nullptr, *d_crow = nullptr;
@@ -246,6 +273,7 @@ struct gpv_plan {
     PostGraph pgraph[2];
     double *d_nug_post = nullptr;                    // [Nlocs] nuggets in ordering: fixed kernel argument for the graph
     // general-nu Matern: range of pair distances of the plan (parameter independent) and the per-evaluation table
+    double coord_maxabs = 0.0;                       // largest finite |coordinate| (guards the kernel's pre-scaled coordinates)
     double dist_min = 0.0, dist_max = 0.0;
     std::vector<int64_t> dist_hist;                  // point-to-neighbour distances by binary exponent (index = exponent + 1100)
     double *h_mt2[2] = {nullptr, nullptr}, *d_mt2[2] = {nullptr, nullptr};   // pinned staging / device copies, used alternately
@@ -268,6 +296,7 @@ struct gpv_plan {
     int vl_model = -1, vl_cur = 0;
     double vl_alpha = 2.0, vl_sigma = 0.0;
     bool has_z = false, evaluated = false, have_U = false;
+    bool timing = true, timed = false;               // hipEvent pair around the set kernel (gpv_plan_set_kernel_timing)
     hipStream_t last_stream = nullptr;
 };
 
@@ -289,13 +318,22 @@ const char *gpv_status_string(int status)
     }
 }
 
-int gpv_version(void) { return 100; }
+int gpv_version(void) { return 101; }
+
+int gpv_last_hip_error(char *text, int text_len)
+{
+    if (text && text_len > 0) {
+        std::strncpy(text, g_hip_text, (size_t)text_len - 1);
+        text[text_len - 1] = 0;
+    }
+    return g_hip_code;
+}
 
 int gpv_device_count(int *count)
 {
     if (!count) return GPV_ERR_BAD_ARG;
     int c = 0;
-    if (hipGetDeviceCount(&c) != hipSuccess) {
+    if (GPV_HIP_FAILED(hipGetDeviceCount(&c))) {
         *count = 0;
         return GPV_ERR_NO_DEVICE;
     }
@@ -315,7 +353,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
-                    pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags};
+                    pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -324,6 +362,7 @@ int gpv_plan_destroy(gpv_plan *pl)
         if (pl->h_mt2[t]) (void)hipHostFree(pl->h_mt2[t]);
         if (pl->mt_ev[t]) (void)hipEventDestroy(pl->mt_ev[t]);
     }
+    if (pl->h_sums) (void)hipHostFree(pl->h_sums);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
@@ -377,7 +416,7 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
         P = ncolNN;
         generic = true;
     }
-    if (hipSetDevice(device) != hipSuccess) return GPV_ERR_NO_DEVICE;
+    if (GPV_HIP_FAILED(hipSetDevice(device))) return GPV_ERR_NO_DEVICE;
 
     gpv_plan *pl = new gpv_plan();
     pl->device = device;
@@ -391,7 +430,7 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
     pl->generic = generic;
     pl->locs_ld = (dim <= 3) ? 4 : dim;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    if (GPV_HIP_FAILED(hipGetDeviceProperties(&prop, device))) {
         delete pl;
         return GPV_ERR_NO_DEVICE;
     }
@@ -493,6 +532,12 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
     std::vector<double> lr((size_t)Nlocs * pl->locs_ld, 0.0);
     if (locs) {
         const int ld = pl->locs_ld;
+        double mabs = 0.0;
+        for (int64_t i = 0; i < Nlocs * (int64_t)dim; ++i) {
+            const double v = std::fabs(locs[i]);
+            if (v > mabs && v <= 1.79e308) mabs = v;
+        }
+        pl->coord_maxabs = mabs;
         parallel_for(Nlocs, [=, &lr](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i)
                 for (int t = 0; t < dim; ++t) lr[(size_t)np_[i] * ld + t] = locs[i + (int64_t)t * Nlocs];
@@ -541,24 +586,29 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
         gpv_plan_destroy(pl);
         return code;
     };
-    if (hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipEventCreate(&pl->ev0) != hipSuccess || hipEventCreate(&pl->ev1) != hipSuccess) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipStreamCreateWithFlags(&pl->stream, hipStreamNonBlocking))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipEventCreate(&pl->ev0)) || GPV_HIP_FAILED(hipEventCreate(&pl->ev1))) return fail(GPV_ERR_HIP);
     const size_t nnb = nn.size() * sizeof(int32_t), cdb = cd.size(), lrb = lr.size() * sizeof(double);
-    if (hipMalloc((void **)&pl->d_nn, nnb) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_cond, cdb) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_locs, lrb) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_nuggets, sizeof(double) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_block, sizeof(double) * kNSums * (size_t)kMaxGrid) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_sums, sizeof(double) * kNSums) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMemcpy(pl->d_nn, nn.data(), nnb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMemcpy(pl->d_cond, cd.data(), cdb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMemcpy(pl->d_locs, lr.data(), lrb, hipMemcpyHostToDevice) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_rowid, sizeof(int32_t) * rowsrc.size()) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMemcpy(pl->d_rowid, rowsrc.data(), sizeof(int32_t) * rowsrc.size(), hipMemcpyHostToDevice) != hipSuccess)
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_nn, nnb))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_cond, cdb))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_locs, lrb))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_nuggets, sizeof(double) * (size_t)Nlocs))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_block, sizeof(double) * kNSums * (size_t)kMaxGrid))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_sums, sizeof(double) * kNSums))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_ticket, 64)) || GPV_HIP_FAILED(hipMemset(pl->d_ticket, 0, 64)))
         return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_newpos, sizeof(int32_t) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMalloc((void **)&pl->d_stage, sizeof(double) * (size_t)Nlocs) != hipSuccess) return fail(GPV_ERR_HIP);
-    if (hipMemcpy(pl->d_newpos, newpos.data(), sizeof(int32_t) * (size_t)Nlocs, hipMemcpyHostToDevice) != hipSuccess)
+    if (GPV_HIP_FAILED(hipHostMalloc((void **)&pl->h_sums, sizeof(double) * kNSums, hipHostMallocDefault)) ||
+        GPV_HIP_FAILED(hipHostGetDevicePointer((void **)&pl->h_sums_dev, pl->h_sums, 0)))
+        return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMemcpy(pl->d_nn, nn.data(), nnb, hipMemcpyHostToDevice))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMemcpy(pl->d_cond, cd.data(), cdb, hipMemcpyHostToDevice))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMemcpy(pl->d_locs, lr.data(), lrb, hipMemcpyHostToDevice))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_rowid, sizeof(int32_t) * rowsrc.size()))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMemcpy(pl->d_rowid, rowsrc.data(), sizeof(int32_t) * rowsrc.size(), hipMemcpyHostToDevice)))
+        return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_newpos, sizeof(int32_t) * (size_t)Nlocs))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_stage, sizeof(double) * (size_t)Nlocs))) return fail(GPV_ERR_HIP);
+    if (GPV_HIP_FAILED(hipMemcpy(pl->d_newpos, newpos.data(), sizeof(int32_t) * (size_t)Nlocs, hipMemcpyHostToDevice)))
         return fail(GPV_ERR_HIP);
     tm.lap("plan: alloc + H2D");
     pl->h_newpos.swap(newpos);
@@ -634,6 +684,11 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.Lentries = (flags & GPV_WANT_U) ? pl->d_L : nullptr;
     a.aout = (flags & GPV_WANT_DENOM) ? pl->d_avec : nullptr;
     a.block_sums = pl->d_block;
+    a.sums = pl->d_sums;
+    double *const mirror = d_sums_out ? d_sums_out : pl->h_sums_dev;
+    pl->sums_on_host = (d_sums_out == nullptr);
+    a.sums_copy = mirror;
+    a.ticket = pl->d_ticket;
     a.rows = pl->rows;
     a.nlocs = pl->Nlocs;
     a.locs_ld = pl->locs_ld;
@@ -641,6 +696,11 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.cov = cs.cov;
     a.flags = flags;
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
+    // The Matern kernels multiply the coordinates by cA = sqrt(2 nu)/range once per row instead of the distance once per
+    // pair.  Where c * |x| would overflow (range below 1e-300 of the coordinates' magnitude) the reference's own dist/range
+    // is Inf for every pair of distinct points and its covariance NaN (Inf * 0, src/Matern.cpp:52,68,80): all blocks fail.
+    // Same outcome here, through the diagonal.  (nu = 0.5 gives exact zeros there instead, an independent model: not mirrored.)
+    if (cs.cov != COV_DENSE && cs.cov != COV_ESQE && !(std::fabs(cs.cA) * pl->coord_maxabs < 1e300)) a.sig0 = NAN;
     a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0; a.mt_full = 0; a.mt_win = 0;
     if (cs.cov == COV_MATERN_GEN) {
         bessel_tab_fill(cs.sB, a.bt);
@@ -696,15 +756,16 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     } else {
         std::memset(&a.bt, 0, sizeof(a.bt));
     }
-    GPV_HIP(hipEventRecord(pl->ev0, st));
+    if (pl->timing) GPV_HIP(hipEventRecord(pl->ev0, st));
     if (pl->generic) GPV_HIP(launch_sets_generic(pl->P, a, pl->cus, &pl->grid, st));
     else GPV_HIP(launch_sets(pl->P, a, pl->cus, &pl->grid, st));
-    GPV_HIP(hipEventRecord(pl->ev1, st));          // ev0..ev1 brackets the conditioning-set kernel alone
+    if (pl->timing) GPV_HIP(hipEventRecord(pl->ev1, st));   // ev0..ev1 brackets the conditioning-set kernel alone
+    pl->timed = pl->timing;
     if (pl->mt_pending >= 0) {                     // the kernel that reads this evaluation's Matern table has been enqueued
         GPV_HIP(hipEventRecord(pl->mt_ev[pl->mt_pending], st));
         pl->mt_pending = -1;
     }
-    GPV_HIP(launch_reduce_sums(pl->d_block, pl->grid, pl->d_sums, d_sums_out, st));
+    // (the partial sums are totalled by the set kernel's last workgroup: no reduction launch)
     if (flags & GPV_WANT_DENOM) {
         // nuggets as a vector at a fixed address (scalar: broadcast), so that the pass's kernel arguments never change
         if (pl->nug_is_scalar) GPV_HIP(launch_fill(pl->d_nug_post, pl->nug_scalar, pl->Nlocs, st));
@@ -726,7 +787,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             if (e == hipSuccess && pl->top_K > 0)
                 e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, st);
             if (e == hipSuccess)
-                e = launch_sum_pair(pl->d_rdiag, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, d_sums_out, st);
+                e = launch_sum_pair(pl->d_rdiag, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, mirror, st);
             if (want_mean) {
                 if (e == hipSuccess)
                     e = launch_mean_head(pa, pl->d_order2, pl->d_u, pl->d_levptr2, pl->mean_head_levels, st);
@@ -743,7 +804,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         static const bool no_graph = getenv("GPV_NO_GRAPH") != nullptr;
         bool launched = false;
         if (!no_graph && cap == hipStreamCaptureStatusNone) {
-            if (!g.exec || g.sums_out != d_sums_out) {                     // first use, or another mirror address
+            if (!g.exec || g.sums_out != mirror) {                         // first use, or another mirror address
                 if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
                 if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                     const hipError_t e = enqueue();
@@ -751,7 +812,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                     const hipError_t e2 = hipStreamEndCapture(st, &graph);
                     if (e == hipSuccess && e2 == hipSuccess && graph &&
                         hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0) == hipSuccess)
-                        g.sums_out = d_sums_out;
+                        g.sums_out = mirror;
                     else
                         g.exec = nullptr;
                     if (graph) (void)hipGraphDestroy(graph);
@@ -974,8 +1035,8 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     GPV_HIP(hipSetDevice(pl->device));
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-        if (hipMalloc(dst, bytes ? bytes : 8) != hipSuccess) return GPV_ERR_HIP;
-        if (bytes && hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return GPV_ERR_HIP;
+        if (GPV_HIP_FAILED(hipMalloc(dst, bytes ? bytes : 8))) return GPV_ERR_HIP;
+        if (bytes && GPV_HIP_FAILED(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice))) return GPV_ERR_HIP;
         return GPV_OK;
     };
     int rc = GPV_OK;
@@ -1057,9 +1118,20 @@ int gpv_plan_vl_begin(gpv_plan *pl, int model, const double *likparms, const dou
     return GPV_OK;
 }
 
+// one Newton step in two halves, so that several plans (replicas on several GPUs) can have theirs in flight together
+static int vl_step_enqueue(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms);
+static int vl_step_finish(gpv_plan *pl, double *dmax, int *flags);
+
 int gpv_plan_vl_step(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms, double *dmax, int *flags)
 {
     if (!pl || !dmax || !flags) return GPV_ERR_BAD_ARG;
+    const int rc = vl_step_enqueue(pl, covType, covparms, ncovparms);
+    return rc != GPV_OK ? rc : vl_step_finish(pl, dmax, flags);
+}
+
+static int vl_step_enqueue(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms)
+{
+    if (!pl) return GPV_ERR_BAD_ARG;
     if (pl->vl_model < 0) return GPV_ERR_STATE;
     CovSetup cs;
     const int st0 = cov_setup(covType, covparms, ncovparms, cs);
@@ -1078,6 +1150,13 @@ int gpv_plan_vl_step(gpv_plan *pl, const char *covType, const double *covparms, 
     const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_MEAN, st, nullptr);
     if (rc != GPV_OK) return rc;
     GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, st));   // :115-117
+    return GPV_OK;
+}
+
+static int vl_step_finish(gpv_plan *pl, double *dmax, int *flags)
+{
+    GPV_HIP(hipSetDevice(pl->device));
+    hipStream_t st = pl->stream;
     double h_out = 0.0;
     int h_flags = 0;
     GPV_HIP(hipMemcpyAsync(&h_out, pl->d_vl_out, sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1127,6 +1206,11 @@ int gpv_plan_get_sums(gpv_plan *pl, double *sums)
     if (!pl || !sums) return GPV_ERR_BAD_ARG;
     if (!pl->evaluated) return GPV_ERR_STATE;
     GPV_HIP(hipSetDevice(pl->device));
+    if (pl->sums_on_host) {                        // the kernels wrote the totals into pinned host memory
+        GPV_HIP(hipStreamSynchronize(pl->last_stream));
+        std::memcpy(sums, pl->h_sums, sizeof(double) * kNSums);
+        return GPV_OK;
+    }
     GPV_HIP(hipMemcpyAsync(sums, pl->d_sums, sizeof(double) * kNSums, hipMemcpyDeviceToHost, pl->last_stream));
     GPV_HIP(hipStreamSynchronize(pl->last_stream));
     return GPV_OK;
@@ -1184,12 +1268,19 @@ int gpv_plan_rows(gpv_plan *pl, int64_t *row_begin, int64_t *row_end)
 int gpv_plan_last_kernel_ms(gpv_plan *pl, double *ms)
 {
     if (!pl || !ms) return GPV_ERR_BAD_ARG;
-    if (!pl->evaluated) return GPV_ERR_STATE;
+    if (!pl->evaluated || !pl->timed) return GPV_ERR_STATE;
     GPV_HIP(hipSetDevice(pl->device));
     GPV_HIP(hipEventSynchronize(pl->ev1));
     float f = 0.f;
     GPV_HIP(hipEventElapsedTime(&f, pl->ev0, pl->ev1));
     *ms = (double)f;
+    return GPV_OK;
+}
+
+int gpv_plan_set_kernel_timing(gpv_plan *pl, int on)
+{
+    if (!pl) return GPV_ERR_BAD_ARG;
+    pl->timing = on != 0;
     return GPV_OK;
 }
 
@@ -1276,15 +1367,15 @@ static int zentries_host(gpv_plan *pl, const double *nuggets_obsord, int64_t n, 
     }
     double *d_n = nullptr, *d_Z = nullptr;
     GPV_HIP(hipMalloc((void **)&d_n, sizeof(double) * (size_t)n));
-    if (hipMalloc((void **)&d_Z, sizeof(double) * 2 * (size_t)n) != hipSuccess) {
+    if (GPV_HIP_FAILED(hipMalloc((void **)&d_Z, sizeof(double) * 2 * (size_t)n))) {
         (void)hipFree(d_n);
         return GPV_ERR_HIP;
     }
     int rc = GPV_OK;
-    if (hipMemcpyAsync(d_n, nuggets_obsord, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, pl->stream) != hipSuccess ||
-        launch_zentries(d_n, n, d_Z, pl->stream) != hipSuccess ||
-        hipMemcpyAsync(Zentries, d_Z, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, pl->stream) != hipSuccess ||
-        hipStreamSynchronize(pl->stream) != hipSuccess)
+    if (GPV_HIP_FAILED(hipMemcpyAsync(d_n, nuggets_obsord, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, pl->stream)) ||
+        GPV_HIP_FAILED(launch_zentries(d_n, n, d_Z, pl->stream)) ||
+        GPV_HIP_FAILED(hipMemcpyAsync(Zentries, d_Z, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost, pl->stream)) ||
+        GPV_HIP_FAILED(hipStreamSynchronize(pl->stream)))
         rc = GPV_ERR_HIP;
     (void)hipFree(d_n);
     (void)hipFree(d_Z);
@@ -1375,8 +1466,8 @@ void gpv_U_NZentries_mat(const int *Ncores, const int *n, const int *Nlocs, cons
     int rc = gpv_plan_create(&pl, 0, *Nlocs, 1, *ncolNN, nullptr, revNNarray, nullptr, 0, *Nlocs);
     if (rc != GPV_OK) { *status = rc; return; }
     const size_t bytes = sizeof(double) * (size_t)(*Nlocs) * (size_t)(*Nlocs);
-    if (hipMalloc((void **)&pl->d_covvals, bytes) != hipSuccess ||
-        hipMemcpy(pl->d_covvals, covVals, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_covvals, bytes)) ||
+        GPV_HIP_FAILED(hipMemcpy(pl->d_covvals, covVals, bytes, hipMemcpyHostToDevice))) {
         gpv_plan_destroy(pl);
         *status = GPV_ERR_HIP;
         return;
@@ -1400,18 +1491,18 @@ static void covfun_host(const double *distmat, const int *nelem, const CovSetup 
     if (n <= 0) { *status = GPV_OK; return; }
     double *d_in = nullptr, *d_out = nullptr;
     int rc = GPV_OK;
-    if (hipSetDevice(0) != hipSuccess || hipMalloc((void **)&d_in, sizeof(double) * (size_t)n) != hipSuccess) {
+    if (GPV_HIP_FAILED(hipSetDevice(0)) || GPV_HIP_FAILED(hipMalloc((void **)&d_in, sizeof(double) * (size_t)n))) {
         *status = GPV_ERR_HIP;
         return;
     }
-    if (hipMalloc((void **)&d_out, sizeof(double) * (size_t)n) != hipSuccess) {
+    if (GPV_HIP_FAILED(hipMalloc((void **)&d_out, sizeof(double) * (size_t)n))) {
         (void)hipFree(d_in);
         *status = GPV_ERR_HIP;
         return;
     }
-    if (hipMemcpy(d_in, distmat, sizeof(double) * (size_t)n, hipMemcpyHostToDevice) != hipSuccess ||
-        launch_covfun(d_in, n, cs.cov, cs.sig0, cs.sA, cs.cA, cs.sB, cs.cB, d_out, nullptr) != hipSuccess ||
-        hipMemcpy(covmat, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess)
+    if (GPV_HIP_FAILED(hipMemcpy(d_in, distmat, sizeof(double) * (size_t)n, hipMemcpyHostToDevice)) ||
+        GPV_HIP_FAILED(launch_covfun(d_in, n, cs.cov, cs.sig0, cs.sA, cs.cA, cs.sB, cs.cB, d_out, nullptr)) ||
+        GPV_HIP_FAILED(hipMemcpy(covmat, d_out, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost)))
         rc = GPV_ERR_HIP;
     (void)hipFree(d_in);
     (void)hipFree(d_out);
@@ -1449,6 +1540,7 @@ struct gpv_mplan {
     std::vector<gpv_plan *> plans;
     int64_t Nlocs = 0;
     int p = 0;
+    bool replicas = false;        // every plan owns ALL rows (gpv_mplan_create_replicas); else contiguous row shards
 };
 
 int gpv_mplan_create(gpv_mplan **out, const int *devices, int ndev, int64_t Nlocs, int dim, int ncolNN,
@@ -1475,6 +1567,104 @@ int gpv_mplan_create(gpv_mplan **out, const int *devices, int ndev, int64_t Nloc
     return GPV_OK;
 }
 
+// Replicas: what "8 GPUs" means for the parts of the path that do not shard (the posterior pass of cond.yz='SGV', hence
+// every Vecchia-Laplace Newton step, BASELINE.json configs[4]): one COMPLETE plan per device, each evaluating its own
+// parameter vector (the vertices of a simplex, a grid, restarts) or its own data set, all of them in flight together.
+int gpv_mplan_create_replicas(gpv_mplan **out, const int *devices, int ndev, int64_t Nlocs, int dim, int ncolNN,
+                              const double *locs, const int *revNN, const int *revCond)
+{
+    if (!out || !devices || ndev < 1) return GPV_ERR_BAD_ARG;
+    *out = nullptr;
+    gpv_mplan *mp = new gpv_mplan();
+    mp->Nlocs = Nlocs;
+    mp->p = ncolNN;
+    mp->replicas = true;
+    for (int g = 0; g < ndev; ++g) {
+        gpv_plan *pl = nullptr;
+        const int rc = plan_create_impl(&pl, devices[g], Nlocs, dim, ncolNN, locs, revNN, revCond, 0, Nlocs,
+                                        mp->plans.empty() ? nullptr : mp->plans[0]->h_newpos.data());
+        if (rc != GPV_OK) {
+            for (gpv_plan *q : mp->plans) gpv_plan_destroy(q);
+            delete mp;
+            return rc;
+        }
+        mp->plans.push_back(pl);
+    }
+    *out = mp;
+    return GPV_OK;
+}
+
+int gpv_mplan_count(gpv_mplan *mp, int *n)
+{
+    if (!mp || !n) return GPV_ERR_BAD_ARG;
+    *n = (int)mp->plans.size();
+    return GPV_OK;
+}
+
+int gpv_mplan_build_posterior(gpv_mplan *mp, const int *revNN, const int *revCond)
+{
+    if (!mp || !mp->replicas) return GPV_ERR_BAD_ARG;               // row shards cannot run the posterior pass
+    for (gpv_plan *q : mp->plans) {
+        const int rc = gpv_plan_build_posterior(q, revNN, revCond);
+        if (rc != GPV_OK) return rc;
+    }
+    return GPV_OK;
+}
+
+int gpv_mplan_set_data_one(gpv_mplan *mp, int replica, const double *z_ord)
+{
+    if (!mp || !mp->replicas || replica < 0 || replica >= (int)mp->plans.size()) return GPV_ERR_BAD_ARG;
+    return gpv_plan_set_data(mp->plans[(size_t)replica], z_ord);
+}
+
+int gpv_mplan_eval_each(gpv_mplan *mp, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
+                        int flags, double *sums)
+{
+    if (!mp || !mp->replicas || !covparms || !nuggets || !sums || ncovparms < 1) return GPV_ERR_BAD_ARG;
+    const size_t R = mp->plans.size();
+    for (size_t r = 0; r < R; ++r) {                                // every replica is enqueued before any is awaited
+        const int rc = gpv_plan_eval(mp->plans[r], covType, covparms + r * (size_t)ncovparms, ncovparms, nuggets + r, 1, flags,
+                                     nullptr, nullptr);
+        if (rc != GPV_OK) return rc;
+    }
+    for (size_t r = 0; r < R; ++r) {
+        const int rc = gpv_plan_get_sums(mp->plans[r], sums + r * GPV_NSUMS);
+        if (rc != GPV_OK) return rc;
+    }
+    return GPV_OK;
+}
+
+int gpv_mplan_vl_begin_one(gpv_mplan *mp, int replica, int model, const double *likparms, const double *z_ord,
+                           const double *prior_mean_ord, const double *y_init_ord)
+{
+    if (!mp || !mp->replicas || replica < 0 || replica >= (int)mp->plans.size()) return GPV_ERR_BAD_ARG;
+    return gpv_plan_vl_begin(mp->plans[(size_t)replica], model, likparms, z_ord, prior_mean_ord, y_init_ord);
+}
+
+int gpv_mplan_vl_step_each(gpv_mplan *mp, const char *covType, const double *covparms, int ncovparms, const int *active,
+                           double *dmax, int *flags)
+{
+    if (!mp || !mp->replicas || !covparms || !dmax || !flags || ncovparms < 1) return GPV_ERR_BAD_ARG;
+    const size_t R = mp->plans.size();
+    for (size_t r = 0; r < R; ++r) {
+        if (active && !active[r]) continue;
+        const int rc = vl_step_enqueue(mp->plans[r], covType, covparms + r * (size_t)ncovparms, ncovparms);
+        if (rc != GPV_OK) return rc;
+    }
+    for (size_t r = 0; r < R; ++r) {
+        if (active && !active[r]) continue;
+        const int rc = vl_step_finish(mp->plans[r], dmax + r, flags + r);
+        if (rc != GPV_OK) return rc;
+    }
+    return GPV_OK;
+}
+
+int gpv_mplan_vl_get_one(gpv_mplan *mp, int replica, double *mean_ord, double *t_ord, double *D_ord)
+{
+    if (!mp || !mp->replicas || replica < 0 || replica >= (int)mp->plans.size()) return GPV_ERR_BAD_ARG;
+    return gpv_plan_vl_get(mp->plans[(size_t)replica], mean_ord, t_ord, D_ord);
+}
+
 int gpv_mplan_destroy(gpv_mplan *mp)
 {
     if (!mp) return GPV_OK;
@@ -1496,7 +1686,7 @@ int gpv_mplan_set_data(gpv_mplan *mp, const double *z_ord)
 int gpv_mplan_eval(gpv_mplan *mp, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
                    int64_t n_nuggets, int flags, double *sums)
 {
-    if (!mp || !sums) return GPV_ERR_BAD_ARG;
+    if (!mp || !sums || mp->replicas) return GPV_ERR_BAD_ARG;
     if (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN)) return GPV_ERR_BAD_ARG;       // the posterior pass does not shard
     for (gpv_plan *q : mp->plans) {                                              // all devices start before any is awaited
         const int rc = gpv_plan_eval(q, covType, covparms, ncovparms, nuggets, n_nuggets, flags, nullptr, nullptr);
@@ -1515,7 +1705,7 @@ int gpv_mplan_eval(gpv_mplan *mp, const char *covType, const double *covparms, i
 int gpv_mplan_get_Lentries(gpv_mplan *mp, double *Lentries)
 {
     // column-major Nlocs x ncolNN: every device's shard lands in its rows
-    if (!mp || !Lentries) return GPV_ERR_BAD_ARG;
+    if (!mp || !Lentries || mp->replicas) return GPV_ERR_BAD_ARG;
     for (gpv_plan *q : mp->plans) {
         const int64_t rows = q->rows;
         if (rows == 0) continue;

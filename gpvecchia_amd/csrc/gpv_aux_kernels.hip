@@ -1,5 +1,5 @@
 // gpv_aux_kernels.hip — small helper kernels around the conditioning-set kernel:
-// deterministic final reduction, Zentries (src/U_NZentries.cpp:111-115), layout
+// Zentries (src/U_NZentries.cpp:111-115), layout
 // conversion for the column-major R boundary, elementwise MaternFun / EsqeFun.
 #include "gpv_sets_kernel.hpp"
 #include "gpv_plist.h"
@@ -40,42 +40,6 @@ hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStrea
         default:
             return hipErrorInvalidValue;
     }
-}
-
-// ---- final reduction: fixed order => run-to-run deterministic ---------------------------
-__global__ void __launch_bounds__(256) gpv_reduce_sums_kernel(const double *block_sums, int nblocks, double *sums,
-                                                              double *sums_copy)
-{
-    // thread = q + 8*part: 32 strided partial sums per quantity (independent loads in flight),
-    // then a fixed-order combine => bitwise reproducible for a given grid
-    const int q = threadIdx.x & 7, part = threadIdx.x >> 3;
-    // four independent accumulators per thread: the loads of a burst are in flight together (the single-chain
-    // version spent ~250 ns of L2 latency per block partial); fixed association => still reproducible
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int b = part;
-    for (; b + 96 < nblocks; b += 128) {
-        s0 += block_sums[(int64_t)b * kNSums + q];
-        s1 += block_sums[(int64_t)(b + 32) * kNSums + q];
-        s2 += block_sums[(int64_t)(b + 64) * kNSums + q];
-        s3 += block_sums[(int64_t)(b + 96) * kNSums + q];
-    }
-    for (; b < nblocks; b += 32) s0 += block_sums[(int64_t)b * kNSums + q];
-    const double s = (s0 + s1) + (s2 + s3);
-    __shared__ double sh[256];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x < kNSums) {
-        double t = 0.0;
-        for (int p2 = 0; p2 < 32; ++p2) t += sh[p2 * 8 + threadIdx.x];
-        sums[threadIdx.x] = t;
-        if (sums_copy != nullptr) sums_copy[threadIdx.x] = t;
-    }
-}
-
-hipError_t launch_reduce_sums(const double *block_sums, int nblocks, double *sums, double *sums_copy, hipStream_t s)
-{
-    hipLaunchKernelGGL(gpv_reduce_sums_kernel, dim3(1), dim3(256), 0, s, block_sums, nblocks, sums, sums_copy);
-    return hipGetLastError();
 }
 
 __global__ void gpv_fill_kernel(double *dst, double value, int64_t n)

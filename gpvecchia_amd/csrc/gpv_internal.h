@@ -28,7 +28,10 @@ struct SetArgs {
     const double *covvals;   // COV_DENSE: [Nlocs][Nlocs] symmetric covariance (U_NZentries_mat) or nullptr
     double *Lentries;        // [rows][P] row-major, left-aligned, or nullptr
     double *aout;            // [rows] a_k = sum_j M_j z_j over observed-conditioned neighbours (R/vecchia_likelihood.R:74) or nullptr
-    double *block_sums;      // [grid][kNSums]
+    double *block_sums;      // [grid][kNSums] per-workgroup partial sums
+    double *sums;            // [kNSums] their fixed-order total, written by the workgroup that finishes last (gpv_reduce_tail.hpp)
+    double *sums_copy;       // second destination of the totals (the caller's all-reduce buffer) or nullptr
+    unsigned *ticket;        // arrival counter of the launch's workgroups; zero between launches
     int64_t rows;            // conditioning sets in this launch
     int64_t nlocs;
     int locs_ld;             // doubles per location in `locs`
@@ -55,7 +58,6 @@ int pick_P(int p);
 int max_P();
 
 // small helper kernels (gpv_aux_kernels.hip)
-hipError_t launch_reduce_sums(const double *block_sums, int nblocks, double *sums, double *sums_copy, hipStream_t s);
 hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);
 // dst[pos[i] * stride + offset] = src[i]
 hipError_t launch_scatter(const double *src, const int32_t *pos, int64_t n, double *dst, int stride, int offset, hipStream_t s);

@@ -6,6 +6,7 @@
 // column-oriented back-substitution for R x = e_last (src/U_NZentries.cpp:57-62).  Same inputs, outputs, failure
 // semantics and partial sums as gpv_sets_kernel (gpv_sets_kernel.hpp).
 #include "gpv_sets_kernel.hpp"
+#include <atomic>
 
 namespace gpv {
 
@@ -172,7 +173,10 @@ __global__ void __launch_bounds__(kGenericThreads) gpv_sets_generic_kernel(const
         __syncthreads();
     }
     if (tid == 0)
-        for (int t = 0; t < kNSums; ++t) A.block_sums[(int64_t)blockIdx.x * kNSums + t] = acc[t];
+        for (int t = 0; t < kNSums; ++t) s_red[t] = acc[t];
+    __syncthreads();
+    const double mine = tid < kNSums ? s_red[tid] : 0.0;
+    reduce_tail<kGenericThreads>(A, mine, s_red, &s_fail);
 }
 
 int generic_max_P() { return kGenericMaxP; }
@@ -181,11 +185,16 @@ hipError_t launch_sets_generic(int P, const SetArgs &a, int cus, int *grid_out, 
 {
     if (P < 1 || P > kGenericMaxP) return hipErrorInvalidValue;
     const size_t smem = sizeof(double) * ((size_t)P * (P + 1) / 2 + 2 * (size_t)P) + sizeof(int) * 2 * (size_t)P;
-    static bool attr_done = false;                                   // > 64 KiB of dynamic LDS needs the opt-in
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_sets_generic_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
-        attr_done = true;
+    // > 64 KiB of dynamic LDS needs the opt-in, once per DEVICE (a gpv_mplan drives several from one process)
+    static std::atomic<unsigned long long> attr_done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_sets_generic_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (e != hipSuccess) return e;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     int64_t grid = a.rows < 1 ? 1 : a.rows;
     const int64_t cap = (int64_t)cus * 8;

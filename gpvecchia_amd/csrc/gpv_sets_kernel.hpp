@@ -34,6 +34,7 @@
 #pragma once
 #include "gpv_internal.h"
 #include "gpv_bessel.hpp"
+#include "gpv_reduce_tail.hpp"
 #include <type_traits>
 #include <utility>
 
@@ -51,6 +52,25 @@
 #endif
 #ifndef GPV_CHUNK
 #define GPV_CHUNK 8           // pivot-row values fetched per LDS burst in the sweep
+#endif
+// Round-3 instruction diet of the covariance rounds and the sweep (each measured on its own; 0 = the round-2 code)
+#ifndef GPV_OPT_PRESCALE
+#define GPV_OPT_PRESCALE 1    // coordinates multiplied by sqrt(2 nu)/range once per row slot: no t = dist * c per pair
+#endif
+#ifndef GPV_OPT_R2TINY
+#define GPV_OPT_R2TINY 1      // squared distance accumulated from the smallest normal number instead of clamped there afterwards
+#endif
+#ifndef GPV_OPT_SQRT6
+#define GPV_OPT_SQRT6 1       // square root: one third-order step on the v_rsq_f64 seed (6 instructions) instead of Goldschmidt + residual (7)
+#endif
+#ifndef GPV_OPT_LN2ONE
+#define GPV_OPT_LN2ONE 1      // exp: argument reduction with one FMA against ln 2 rounded to double (absolute error < 2^-55 sigma^2)
+#endif
+#ifndef GPV_OPT_XYEXT
+#define GPV_OPT_XYEXT 1       // staged coordinates followed by a copy of the first P/2 rows: partner (r+s) never wraps, no select per fetch
+#endif
+#ifndef GPV_OPT_RCP3
+#define GPV_OPT_RCP3 1        // pivot reciprocal: one third-order step on the v_rcp_f64 seed (3 FMAs) instead of two Newton steps (4)
 #endif
 
 namespace gpv {
@@ -163,7 +183,12 @@ struct SetsLds {
     double tri[SPW][TRI];        // packed lower triangle (diagonal included): (hi,lo) at hi(hi+1)/2+lo
     static constexpr int NCOL = G::DPP ? 1 : 2;
     double col[NCOL][SPW][COLS]; // LDS sweep: pivot-row exchange, double buffered; the last one doubles as the data-row staging
-    double xy[SPW][P][DS];       // staged coordinates
+    // staged coordinates; with XYEXT rows P .. P+P/2-1 repeat rows 0 .. P/2-1, so that the circulant partner (r + s) mod P
+    // of the covariance rounds is simply row r + s
+    // (not for the general-nu variant: there every spare byte of LDS holds rows of the Matern table)
+    static constexpr bool XYEXT = GPV_OPT_XYEXT != 0 && D != 0 && COV != COV_DENSE && COV != COV_MATERN_GEN;
+    static constexpr int XYROWS = XYEXT ? P + P / 2 : P;
+    double xy[SPW][XYROWS][DS];
     static constexpr bool NEEDZERO = G::SLOTS > P + (G::ZROW ? 1 : 0);
     double zero[NEEDZERO ? COLS : 2];   // source of the padding rows beyond the data row
     double acc[SPW][kNSums];     // per-set running partial sums
@@ -234,17 +259,37 @@ __device__ __forceinline__ double rcp_pivot_bounded(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
     double e = __builtin_fma(-x, r, 1.0);
+#if GPV_OPT_RCP3
+    // 1/x = r0 / (1 - e) = r0 (1 + e + e^2 + ...), e ~ 2^-23 for the hardware seed: the e^3 term is below 2^-68
+    const double t = __builtin_fma(e, e, e);
+    return __builtin_fma(r, t, r);
+#else
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-x, r, 1.0);
     r = __builtin_fma(r, e, r);
     return r;
+#endif
 }
 
 // sqrt(x), x > 0 normal: v_rsq_f64 seed + one Goldschmidt step on g + one residual step
 // (error ~1 ulp; x == 0 gives NaN, callers select the dist==0 value separately).
+__device__ __forceinline__ double fma_vs_half(double a, double b)          // a * b + 0.5, b wave-uniform (SGPR pair)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, 0.5" : "=v"(d) : "v"(a), "s"(b));
+    return d;
+}
 __device__ __forceinline__ double sqrt_pos(double x)
 {
     const double y = __builtin_amdgcn_rsq(x);
+#if GPV_OPT_SQRT6
+    // sqrt(x) = g (1 - e)^(-1/2) with g = x y, e = 1 - x y^2 ~ 2^-23: g (1 + e/2 + 3 e^2/8), the e^3 term is below 2^-70.
+    // e is taken against the ROUNDED g, which cancels half of g's own rounding error: the result errs by < 1 ulp.
+    const double g0 = x * y;
+    const double e0 = __builtin_fma(-g0, y, 1.0);
+    const double c0 = fma_vs_half(e0, 0.375);
+    return __builtin_fma(g0 * e0, c0, g0);
+#endif
     double g = x * y;
     double h = 0.5 * y;
     const double r = __builtin_fma(-h, g, 0.5);
@@ -335,13 +380,21 @@ __device__ __forceinline__ ExpScaled exp_scaled_setup(const double scale)
     E.c[10] = E.c[11] = sgpr_f64(scale);
     return E;
 }
+template <bool CLAMP = true>
 __device__ __forceinline__ double exp_neg_scaled(double t, const ExpScaled &E)
 {
-    t = __builtin_fmin(t, 1000.0);
+    if constexpr (CLAMP) t = __builtin_fmin(t, 1000.0);
     const double kk = __builtin_fma(t, -1.4426950408889634, 0x1.8p52);
     const double kd = kk - 0x1.8p52;
+#if GPV_OPT_LN2ONE
+    // one FMA against ln 2 rounded to double (off by 2.3e-17): r errs by 2.3e-17 |k|, the value by 2.3e-17 |k| 2^-|k| sigma^2
+    // <= 1.2e-17 sigma^2 in absolute terms (k = round(-t / ln 2) <= 0): a tenth of the rounding error of sigma^2 itself.  The
+    // relative error of a far pair's tiny covariance grows with |k|; the factorisation only sees the absolute one.
+    const double r = __builtin_fma(kd, -0.693147180559945309417, -t);
+#else
     double r = __builtin_fma(kd, -6.93147180369123816490e-01, -t);
     r = __builtin_fma(kd, -1.90821492927058770002e-10, r);
+#endif
     double p = fma_vvs(E.c[0], r, E.c[1]);
 #pragma unroll
     for (int i = 2; i < 12; ++i) p = fma_vvs(p, r, E.c[i]);
@@ -355,8 +408,10 @@ __device__ __forceinline__ double exp_neg_scaled(double t, const ExpScaled &E)
 struct LogAcc {
     double prod = 0.5;
     int esum = 1;                                   // log(0.5 * 2^1) = 0
+    bool neg = false;                               // a negative factor: log() of it is NaN, whatever the sign of the product
     __device__ __forceinline__ void mul(double x, bool on)
     {
+        neg = neg | (on && x < 0.0);
         const double m = on ? __builtin_amdgcn_frexp_mant(x) : 1.0;      // [0.5, 1); 1.0 = neutral (renormalised below)
         const int e = on ? __builtin_amdgcn_frexp_exp(x) : 0;
         double p = prod * m;                                              // [0.25, 1]
@@ -364,7 +419,10 @@ struct LogAcc {
         prod = __builtin_ldexp(p, up);
         esum += e - up;
     }
-    __device__ __forceinline__ double value() const { return log(prod) + (double)esum * 0.6931471805599453094; }
+    __device__ __forceinline__ double value() const
+    {
+        return neg ? __builtin_nan("") : log(prod) + (double)esum * 0.6931471805599453094;
+    }
 };
 
 // 1/x to ~1 ulp for the likelihood terms: v_rcp_f64 + two Newton steps; x = 0 -> Inf and x = Inf -> 0 survive (the
@@ -392,32 +450,31 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
     return matern_general_tab(bt, s, normcon, nu);
 }
 
-// the same when the host has vouched that the table covers every pair distance of the plan (SetArgs::mt_full): no
-// per-lane range test, hence no divergent branch in the covariance rounds; the segment index is clamped only so that a
-// NaN / zero distance (whose value is discarded by the caller's dist == 0 select or poisons the block anyway) reads
-// inside the table
+// the same when the table spans the distance range the host derived from the plan (SetArgs::mt_full).  That range comes
+// from the point-to-neighbour distances; the kernel also evaluates neighbour-to-neighbour pairs, which stay inside it for
+// true nearest-predecessor arrays but need not for arrays a caller supplies.  A wave whose 64 segments all sit in the LDS
+// window (the common case) is inside the table by construction and takes no range test; on the global-memory path
+// every lane tests its own segment and a pair outside the table is evaluated by the series (`live` = the pair's value is
+// used: a zero distance is replaced by sigma^2 by the caller and only needs a readable row).
 template <int MTW>
-__device__ __forceinline__ double matern_table_only(const double *mt, int mt_base, int mt_nseg, int mt_win, const double *mt_lds,
-                                                    double s, const ExpScaled &E)
+__device__ __forceinline__ double matern_table_only(const SetArgs &A, const double *mt_lds, double s, bool live, const ExpScaled &E)
 {
-    int seg = matern_tab_segment(s, mt_base);
-    seg = seg < 0 ? 0 : (seg >= mt_nseg ? mt_nseg - 1 : seg);
-    double2 q0, q1, q2, q3, q4, q5;
-    bool from_lds = false;
+    const int seg0 = matern_tab_segment(s, A.mt_base);
     if constexpr (MTW > 0) {
-        const int rel = seg - mt_win;
+        const int rel = seg0 - A.mt_win;
         const bool in = (unsigned)rel < (unsigned)MTW;
         if (__builtin_amdgcn_ballot_w64(!in) == 0) {                // wave uniform: every lane's segment sits in the LDS window
             const double2 *row = reinterpret_cast<const double2 *>(mt_lds + rel * kMtRowLds);
-            q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5];
-            from_lds = true;
+            const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
+            return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
         }
     }
-    if (!from_lds) {
-        const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
-        q0 = row[0]; q1 = row[1]; q2 = row[2]; q3 = row[3]; q4 = row[4]; q5 = row[5];
-    }
-    return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
+    const bool inside = (unsigned)seg0 < (unsigned)A.mt_nseg;
+    if (live && !inside) return matern_general_tab(A.bt, s, A.sA, A.sB);   // rare, divergent: a pair the table does not cover
+    const int seg = seg0 < 0 ? 0 : (seg0 >= A.mt_nseg ? A.mt_nseg - 1 : seg0);
+    const double2 *row = reinterpret_cast<const double2 *>(A.mt + (size_t)seg * MaternTab::ROW);
+    const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
+    return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);
 }
 
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
@@ -448,27 +505,41 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // the same for the closed-form families without the dist == 0 select (5 VALU ops per pair): the squared distance
 // is clamped at the smallest normal number instead, where every closed form returns sigma^2 exactly
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
-template <int COV, bool TAB = false, int MTW = 0>
+// SCALED: the coordinates were multiplied by cA (= sqrt(2 nu)/range) when they were gathered, sqrt(r2) is t itself;
+// R2MIN: r2 was accumulated from the smallest normal number (coincident points give exactly that), no clamp needed
+template <int COV, bool TAB = false, int MTW = 0, bool SCALED = false, bool R2MIN = false>
 __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
                                              const SetArgs &A, const ExpScaled &E, const double *mt_lds = nullptr)
 {
+    constexpr double kTiny = 2.2250738585072014e-308;
     if constexpr (COV == COV_MATERN_GEN && TAB) {
-        const double v = matern_table_only<MTW>(A.mt, A.mt_base, A.mt_nseg, A.mt_win, mt_lds,
-                                                sqrt_pos(__builtin_fmax(r2, 2.2250738585072014e-308)) * cA, E);
-        return (r2 == 0.0) ? sig0 : v;                               // src/Matern.cpp:76
+        const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
+        const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
+        // (s clamped for the same reason as t below; s^nu K_nu(s) is 0 in FP64 from s ~ 800 for every nu <= 60)
+        const double v = matern_table_only<MTW>(A, mt_lds, __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4), live, E);
+        return live ? v : sig0;                                      // src/Matern.cpp:76
+    }
+    if constexpr (COV == COV_MATERN_GEN && (SCALED || R2MIN)) {      // series path on prepared operands
+        const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
+        const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
+        const double v = matern_general_seg(A.mt, A.mt_base, A.mt_nseg, A.bt, __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4), sA, sB);
+        return live ? v : sig0;
     }
     if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
-    r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
+    if constexpr (!R2MIN) r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
     const double dist = sqrt_pos(r2);
+    // t is clamped HERE, before its polynomial use as well: v_min_f64 returns 1000 for a NaN, and the only NaN that can reach
+    // this point is Inf * 0 out of the square root of an overflowed squared distance (NaN / Inf coordinates and a NaN range
+    // were turned into a NaN diagonal), where the covariance of the reference is exp(-Inf) = 0 like the clamped value's
     if constexpr (COV == COV_MATERN15) {
-        const double t = dist * cA;
-        const double e = exp_neg_scaled(t, E);       // sigma^2 exp(-t)
+        const double t = __builtin_fmin(SCALED ? dist : dist * cA, 1000.0);
+        const double e = exp_neg_scaled<false>(t, E);       // sigma^2 exp(-t)
         return __builtin_fma(t, e, e);
     } else if constexpr (COV == COV_MATERN05) {
-        return exp_neg_scaled(dist * cA, E);
+        return exp_neg_scaled<true>(SCALED ? dist : dist * cA, E);
     } else if constexpr (COV == COV_MATERN25) {
-        const double t = dist * cA;
-        return exp_neg_scaled(t, E) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
+        const double t = __builtin_fmin(SCALED ? dist : dist * cA, 1000.0);
+        return exp_neg_scaled<false>(t, E) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);
     } else {
         return __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));
     }
@@ -554,6 +625,10 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     // DPP geometries, location records: the records of the next task are requested from the middle of the sweep, when half
     // of the block's registers are free again and nothing else is in flight
     constexpr bool PFREC = G::DPP && D != 0 && COV != COV_DENSE;
+    // formula covariances whose only use of the coordinates is c * dist: the staged coordinates carry the factor
+    constexpr bool PRESCALE = GPV_OPT_PRESCALE != 0 && D != 0 &&
+                              (COV == COV_MATERN05 || COV == COV_MATERN15 || COV == COV_MATERN25 || COV == COV_MATERN_GEN);
+    constexpr bool R2MIN = GPV_OPT_R2TINY != 0 && D != 0 && COV != COV_DENSE;
     double2 pr0[RPL], pr1[RPL];
     double pnug[RPL];
     auto load_rec = [&]() __attribute__((always_inline)) {
@@ -588,7 +663,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             idx[q] = pidx[q];
             cnd[q] = pcnd[q];
             valid[q] = idx[q] >= 0;
-            poison[q] = false;                                // NaN coordinate => NaN block => "Cholesky failed"
+            poison[q] = false;                                // non-finite coordinate => NaN block => "Cholesky failed"
             nugraw[q] = 0.0;
             zi[q] = 0.0;
             if (valid[q] && COV != COV_DENSE) {
@@ -596,7 +671,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     const double *lp = A.locs + (int64_t)idx[q] * A.locs_ld;
                     for (int t = 0; t < A.dim; ++t) {
                         const double c = lp[t];
-                        poison[q] = poison[q] | (c != c);
+                        poison[q] = poison[q] | ((c - c) != 0.0);        // NaN or +-Inf
                         L.xy[sub][row[q]][t] = c;
                     }
                     if (A.z != nullptr) zi[q] = A.z[idx[q]];
@@ -626,10 +701,20 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             vmask[q] = __ballot(valid[q]);
             if constexpr (D != 0) {
 #pragma unroll
-                for (int t = 0; t < D; ++t) poison[q] = poison[q] | (xi[q][t] != xi[q][t]);
+                for (int t = 0; t < D; ++t) poison[q] = poison[q] | ((xi[q][t] - xi[q][t]) != 0.0);   // NaN or +-Inf
+                if constexpr (PRESCALE) {                        // t = sqrt(2 nu) dist / range = |c x_r - c x_j|: once per slot
+#pragma unroll
+                    for (int t = 0; t < D; ++t) xi[q][t] *= cA;
+                }
                 if (lane_on && row[q] < P) {
 #pragma unroll
                     for (int t = 0; t < D; ++t) L.xy[sub][row[q]][t] = xi[q][t];
+                }
+                if (Lds::XYEXT && q * LPS < P / 2) {            // rows 0 .. P/2-1 once more behind row P-1 (folds after unrolling)
+                    if (lane_on && row[q] < P / 2) {
+#pragma unroll
+                        for (int t = 0; t < D; ++t) L.xy[sub][row[q] + P][t] = xi[q][t];
+                    }
                 }
             }
             if (COV == COV_DENSE && lane_on && row[q] < P) L.ix[sub][row[q]] = idx[q];
@@ -731,7 +816,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 trB[q] = rt8 + rq8[q] - 8 * P;
             }
             auto fetch = [&](int q, int s, double (&dst)[DD]) {
-                const lds_cdouble *xj = lds_ptr(((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * DS * 8);
+                const lds_cdouble *xj = Lds::XYEXT ? lds_ptr(xoA[q] + s * DS * 8)
+                                                   : lds_ptr(((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * DS * 8);
 #pragma unroll
                 for (int t = 0; t < D; ++t) dst[t] = xj[t];
             };
@@ -753,13 +839,13 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 double v[RPL];
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
-                    double r2 = 0.0;
+                    double r2 = R2MIN ? 2.2250738585072014e-308 : 0.0;
 #pragma unroll
                     for (int t = 0; t < D; ++t) {
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV, TAB, MTW>(r2, sig0, sA, cA, sB, cB, A, expS, mt_lds);
+                    v[q] = cov_closed<COV, TAB, MTW, PRESCALE, R2MIN>(r2, sig0, sA, cA, sB, cB, A, expS, mt_lds);
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;
@@ -1016,14 +1102,18 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         ac[7] = (double)acc_rows;
     }
 
-    // ---- deterministic block reduction of the partial sums ----------------------------
+    // ---- deterministic reduction of the partial sums: workgroup, then (last workgroup to arrive) the whole launch ----
     __syncthreads();
+    double s = 0.0;
     if (threadIdx.x < kNSums) {
-        double s = 0.0;
         for (int w2 = 0; w2 < W; ++w2)
             for (int s2 = 0; s2 < SPW; ++s2) s += lds_all[w2].acc[s2][threadIdx.x];
-        A.block_sums[(int64_t)blockIdx.x * kNSums + threadIdx.x] = s;
     }
+    // scratch: the waves' LDS blocks, which nobody reads any more (barrier above; the sums were taken into registers)
+    static_assert(sizeof(Lds) * W >= sizeof(double) * (W * 64 + 1), "LDS scratch of the final reduction");
+    double *scratch = reinterpret_cast<double *>(&lds_all[0]);
+    __syncthreads();
+    reduce_tail<W * 64>(A, s, scratch, reinterpret_cast<int *>(scratch + W * 64));
 }
 
 template <int P, int D, int COV>

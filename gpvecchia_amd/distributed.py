@@ -77,6 +77,7 @@ class ShardedLikelihood:
             self._stream = torch.cuda.Stream(device=device)
             self._d = torch.zeros(NSUMS, dtype=torch.float64, device=f"cuda:{device}")
             self._h = torch.zeros(NSUMS, dtype=torch.float64).pin_memory()
+            self._done = torch.cuda.Event()
         self.plan.set_data(z_ord)
 
     def sums(self, covmodel, covparms, nuggets, flags):
@@ -88,7 +89,9 @@ class ShardedLikelihood:
                                d_sums_out=self._d.data_ptr())
                 dist.all_reduce(self._d, op=dist.ReduceOp.SUM, group=self.group)   # the ONE collective: 64 bytes
                 self._h.copy_(self._d, non_blocking=True)
-            self._stream.synchronize()
+                self._done.record(self._stream)
+            while not self._done.query():              # poll the event's flag: a blocking wait costs an interrupt wake-up
+                pass
             return self._h.numpy().copy()
         self.plan.eval(covmodel, covparms, nuggets, flags)
         s = np.asarray(self.plan.sums(), dtype=np.float64)

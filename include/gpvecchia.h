@@ -73,6 +73,11 @@ enum {
 typedef struct gpv_plan gpv_plan;
 
 const char *gpv_status_string(int status);
+/* GPV_ERR_HIP collapses every HIP runtime failure (out of memory, invalid stream, failed launch ...).  This returns the
+ * hipError_t of the last such failure seen by the CALLING host thread (0 = none so far) and, when text != NULL, copies
+ * "<hipError name>: <HIP's description> [<failing call>, file:line]" into text (NUL-terminated, at most text_len bytes).
+ * The reference reports native failures as R errors carrying the C++ exception text (src/RcppExports.cpp:52,66). */
+int gpv_last_hip_error(char *text, int text_len);
 int gpv_version(void);                 /* 100*major + minor */
 int gpv_device_count(int *count);      /* number of visible HIP devices */
 int gpv_max_p(void);                   /* widest supported row length m+1 (192) */
@@ -201,6 +206,10 @@ int gpv_plan_Lentries_device(gpv_plan *plan, double **d_ptr, int64_t *ld);
 int gpv_plan_rows(gpv_plan *plan, int64_t *row_begin, int64_t *row_end);
 /* milliseconds the last eval's conditioning-set kernel took on the device (hipEvent pair around that launch) */
 int gpv_plan_last_kernel_ms(gpv_plan *plan, double *ms);
+/* on = 0: evaluations no longer record that event pair (two queue packets per evaluation; they matter only when an
+ * evaluation is a fraction of a millisecond, e.g. one rank's shard of an 8-GPU job) and gpv_plan_last_kernel_ms returns
+ * GPV_ERR_STATE; default on */
+int gpv_plan_set_kernel_timing(gpv_plan *plan, int on);
 
 /* cond.yz='z' log-likelihood from the (all-reduced) sums; n = number of observations.
  * Closed form of R/vecchia_likelihood.R:63-99 when W = U_y U_y^T is diagonal.
@@ -225,6 +234,32 @@ int gpv_mplan_set_data(gpv_mplan *mplan, const double *z_ord);
 int gpv_mplan_eval(gpv_mplan *mplan, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
                    int64_t n_nuggets, int flags, double *sums /* GPV_NSUMS, host */);
 int gpv_mplan_get_Lentries(gpv_mplan *mplan, double *Lentries /* Nlocs x ncolNN col-major */);
+
+/* REPLICAS: one COMPLETE plan (all rows) per listed device.  This is what several GPUs mean for the parts of the path that
+ * do not shard -- the posterior pass U2V of cond.yz='SGV' (R/vecchia_prediction.R:62-83) and therefore every Newton step of
+ * vecchia_laplace_likelihood (R/vecchia_laplace_NR.R:88-130; BASELINE.json configs[4]): each device evaluates ITS OWN
+ * parameter vector (simplex vertices, grid points, restarts of vecchia_estimate) or its own data set, all in flight
+ * together.  gpv_mplan_eval / gpv_mplan_get_Lentries are for row shards and refuse a replica set; the functions below
+ * refuse a sharded one.  `devices` may name a device more than once.
+ *   gpv_mplan_set_data            the same ordered data on every replica
+ *   gpv_mplan_set_data_one        ordered data of one replica
+ *   gpv_mplan_build_posterior     gpv_plan_build_posterior on every replica
+ *   gpv_mplan_eval_each           covparms: count x ncovparms (row r = replica r), nuggets: one constant nugget per replica,
+ *                                 sums: count x GPV_NSUMS out; every replica is enqueued before any is awaited
+ *   gpv_mplan_vl_begin_one / _vl_step_each / _vl_get_one   the Vecchia-Laplace loop of gpv_plan_vl_*, the Newton steps of all
+ *                                 ACTIVE replicas (active[r] != 0, NULL = all) in flight together; dmax / flags: one per replica */
+int gpv_mplan_create_replicas(gpv_mplan **mplan, const int *devices, int ndev, int64_t Nlocs, int dim, int ncolNN,
+                              const double *locs, const int *revNNarray, const int *revCondOnLatent);
+int gpv_mplan_count(gpv_mplan *mplan, int *n);
+int gpv_mplan_set_data_one(gpv_mplan *mplan, int replica, const double *z_ord);
+int gpv_mplan_build_posterior(gpv_mplan *mplan, const int *revNNarray, const int *revCondOnLatent);
+int gpv_mplan_eval_each(gpv_mplan *mplan, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
+                        int flags, double *sums);
+int gpv_mplan_vl_begin_one(gpv_mplan *mplan, int replica, int model, const double *likparms, const double *z_ord,
+                           const double *prior_mean_ord, const double *y_init_ord);
+int gpv_mplan_vl_step_each(gpv_mplan *mplan, const char *covType, const double *covparms, int ncovparms, const int *active,
+                           double *dmax, int *flags);
+int gpv_mplan_vl_get_one(gpv_mplan *mplan, int replica, double *mean_ord, double *t_ord, double *D_ord);
 
 /* -------------------------------------------------------------------------
  * Host-side setup helper (no GPU needed, parameter independent, once per data set).

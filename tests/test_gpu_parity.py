@@ -1100,3 +1100,171 @@ def test_ill_conditioned_rows_normwise():
     err_gpu = np.abs(out["Lentries"][k] - x).max() / np.abs(x).max()
     err_ref = np.abs(ref["Lentries"][k] - x).max() / np.abs(x).max()
     assert err_gpu < max(10 * err_ref, 1e-9)
+
+
+# ---------------------------------------------------------------------------
+# round 3: the set kernel totals its own partial sums (last workgroup to arrive), error text, NaN parameters
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n,m", [(300, 3), (20000, 10), (150000, 30), (60000, 60)])
+def test_fused_reduction_is_reproducible_and_never_stale(n, m):
+    """The totals come from the workgroup that happens to finish last; they must not depend on which one that is, and a
+    launch must never see partial sums of the launch before it (same buffers, other parameters): A, B, A, B ... on one
+    plan gives bitwise the same two answers every time, and each equals a fresh plan's."""
+    G = _need_gpu()
+    from gpvecchia_amd import specify as S
+    rng = np.random.default_rng(n + m)
+    d = 3 if m == 60 else 2
+    locs = rng.random((n, d))
+    z = rng.standard_normal(n)
+    NN = S.find_ordered_nn_gpu(locs, m)
+    revNN = NN[:, ::-1].copy()
+    revCond = np.where(revNN != 0, 0, -1).astype(np.int8)
+    revCond[:, -1] = 1
+    pA, pB = ([1.0, 0.05, 1.5], 0.1), ([2.5, 0.11, 0.5], 0.7)
+    flags = G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_NUMERATOR
+
+    def fresh(par):
+        pl = G.Plan(locs, revNN, revCond)
+        pl.set_data(z)
+        pl.eval("matern", par[0], par[1], flags)
+        return pl.sums()
+    sA, sB = fresh(pA), fresh(pB)
+    assert sA[7] == n and sB[7] == n and sA[6] == 0 and not np.array_equal(sA[:6], sB[:6])
+    plan = G.Plan(locs, revNN, revCond)
+    plan.set_data(z)
+    for it in range(12):
+        par, ref = (pA, sA) if it % 2 == 0 else (pB, sB)
+        plan.eval("matern", par[0], par[1], flags)
+        np.testing.assert_array_equal(plan.sums(), ref)
+    # back to back without reading in between (the stream orders the launches; the ticket must be back at zero each time)
+    for it in range(6):
+        plan.eval("matern", pA[0], pA[1], flags)
+    plan.eval("matern", pB[0], pB[1], flags)
+    np.testing.assert_array_equal(plan.sums(), sB)
+    # the closed-form likelihood from the fused totals against the per-row definition on the host
+    plan.eval("matern", pA[0], pA[1], G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
+    Lent = plan.Lentries()
+    dk = Lent[np.arange(n), (revNN != 0).sum(axis=1) - 1]
+    np.testing.assert_allclose(plan.sums()[2], np.sum(np.log(pA[1] + 1.0 / dk ** 2)), rtol=1e-11)
+
+
+def test_last_hip_error_is_retrievable():
+    """GPV_ERR_HIP alone does not say what failed: the HIP error name, text and failing call are kept per thread.
+    Provoked with a dense covariance matrix (U_NZentries_mat) larger than the GPU's memory: the allocation fails before
+    the library reads a byte of it."""
+    G = _need_gpu()
+    import ctypes as C
+    from gpvecchia_amd import _lib as L
+    n, p = 250_000, 2                                 # n^2 doubles = 500 GB > 288 GB
+    nn = np.zeros((n, p), dtype=np.int32, order="F")
+    nn[:, -1] = np.arange(1, n + 1)
+    nugo = np.full(n, 0.1)
+    cv = np.zeros(16)                                 # never read: hipMalloc fails first
+    Lent = np.zeros((n, p), order="F")
+    Z = np.zeros(2 * n)
+    ci = lambda v: C.byref(C.c_int(int(v)))
+    nfail, status = C.c_int(0), C.c_int(0)
+    L.lib().gpv_U_NZentries_mat(ci(1), ci(n), ci(n), ci(p), L.iptr(nn), L.dptr(nugo), L.dptr(cv), L.dptr(Lent), L.dptr(Z),
+                                C.byref(nfail), C.byref(status))
+    assert status.value == 6                          # GPV_ERR_HIP
+    buf = C.create_string_buffer(256)
+    code = L.lib().gpv_last_hip_error(buf, 256)
+    assert code != 0 and b"hipErrorOutOfMemory" in buf.value and b"hipMalloc" in buf.value and b"gpv_api.hip" in buf.value
+    with pytest.raises(G.GpvError, match="hipErrorOutOfMemory"):
+        L.check(status.value, "gpv_U_NZentries_mat")
+
+
+@pytest.mark.parametrize("nu", [0.5, 1.5, 2.5, 1.2])
+def test_nan_parameters_fail_every_block(nu):
+    """A NaN range or variance makes every covariance NaN in the reference: every block fails, rows stay zero
+    (src/U_NZentries.cpp:64-66), the likelihood is -Inf; the clamped exponent must not turn it into an independent model."""
+    G = _need_gpu()
+    locs, z, va = _case(400, 10, 2, 3, "z")
+    pva = _to_product_va(va)
+    for cp in ([1.0, float("nan"), nu], [float("nan"), 0.1, nu]):
+        U = G.createU(pva, cp, 0.1)
+        assert np.all(U["Lentries"] == 0.0)
+        assert G.vecchia_likelihood(z, pva, cp, 0.1) == -np.inf
+
+
+def test_negative_nuggets_give_nan_logs_whatever_their_count():
+    """log(tau) of a negative nugget is NaN in the reference (R/vecchia_likelihood.R:76: log of a negative diagonal entry);
+    the running-product logarithm must not let two negative factors cancel."""
+    G = _need_gpu()
+    n = 500
+    locs, z, va = _case(n, 8, 2, 9, "z")
+    pva = _to_product_va(va)
+    plan = G.Plan(pva["locsord"], pva["U_prep"]["revNNarray"], pva["U_prep"]["revCond"])
+    plan.set_data(z)
+    for bad in ([7], [7, 8], [3, 90, 91, 400]):
+        tau = np.full(n, 0.3)
+        tau[bad] = -1e-3                              # small enough that every block stays positive definite
+        plan.eval("matern", [1.0, 0.1, 1.5], tau, G.GPV_WANT_NUMERATOR)
+        s = plan.sums()
+        assert s[6] == 0 and np.isnan(s[5]), (bad, s)
+
+
+def test_general_nu_table_with_user_supplied_neighbour_arrays():
+    """gpv_plan_create derives the Matern table's range from point-to-neighbour distances; with arrays that are not nearest
+    predecessors a neighbour-neighbour pair can be closer than any of those and must still be evaluated correctly."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(77)
+    n, m = 600, 6
+    locs = rng.random((n, 2)) * 10.0
+    # two tight clusters far from everything else: their members are each other's "neighbours" only through third points
+    locs[1] = locs[0] + 1e-5
+    locs[3] = locs[2] + 3e-6
+    NN = np.zeros((n, m + 1), dtype=np.int32)
+    NN[:, 0] = np.arange(1, n + 1)
+    for k in range(5, n):
+        far = rng.choice(np.arange(4, k), size=min(m - 4, k - 4), replace=False) + 1
+        NN[k, 1:5] = [1, 2, 3, 4]                      # every later point conditions on both tight pairs
+        NN[k, 5:5 + far.size] = far
+    revNN = NN[:, ::-1].copy()
+    revCond = np.where(revNN != 0, 0, -1).astype(np.int8)
+    revCond[:, -1] = 1
+    tau = 0.05
+    for nu in (0.7, 1.9):
+        cp = [1.3, 2.0, nu]
+        ref = R.U_NZentries(R.max_threads(), n, locs, np.where(revNN == 0, np.nan, revNN.astype(float)),
+                            np.where(revCond < 0, 0, revCond), np.full(n, tau), np.full(n, tau), "matern", cp)
+        plan = G.Plan(locs, revNN, revCond)
+        plan.eval("matern", cp, tau, G.GPV_WANT_U)
+        assert plan.sums()[6] == 0
+        assert _row_err(plan.Lentries(), ref["Lentries"]) < ROW_TOL
+
+
+def test_replica_plans_evaluate_different_parameters_concurrently():
+    """Replica mode of gpv_mplan (one complete plan per device; here device 0 named three times): every replica's
+    likelihood equals the single plan's at the same parameters, for cond.yz='SGV' with the posterior pass (which does not
+    shard: this is what BASELINE configs[4] can use several GPUs for) and for 'z'; shard-only calls refuse a replica set."""
+    G = _need_gpu()
+    n, m = 2500, 12
+    locs, z, va = _case(n, m, 2, 5, "SGV", ordering="maxmin")
+    pva = _to_product_va(va)
+    prep = pva["U_prep"]
+    zo = z[va["ord_z"] - 1]
+    thetas = np.array([[1.0, 0.1, 1.5], [0.7, 0.2, 0.5], [1.9, 0.05, 2.5]])
+    taus = np.array([0.1, 0.3, 0.05])
+    rp = G.ReplicaPlans(pva["locsord"], prep["revNNarray"], prep["revCond"], devices=[0, 0, 0])
+    rp.set_data(zo)
+    ll = rp.logliks("matern", thetas, taus, cond_yz="SGV")
+    for r in range(3):
+        ref = G.vecchia_likelihood(z, pva, thetas[r], taus[r])
+        assert abs(ll[r] - ref) <= 1e-12 * abs(ref), (r, ll[r], ref)
+    # one replica gets other data
+    z2 = np.random.default_rng(1).standard_normal(n)
+    rp.set_data(z2[va["ord_z"] - 1], replica=1)
+    ll2 = rp.logliks("matern", thetas, taus, cond_yz="SGV")
+    assert ll2[0] == ll[0] and ll2[2] == ll[2]
+    ref1 = G.vecchia_likelihood(z2, pva, thetas[1], taus[1])
+    assert abs(ll2[1] - ref1) <= 1e-12 * abs(ref1)
+    import ctypes as C
+    from gpvecchia_amd import _lib as L
+    s = np.zeros(8)
+    cp = np.array([1.0, 0.1, 1.5])
+    tau = np.array([0.1])
+    assert L.lib().gpv_mplan_eval(rp._h, b"matern", L.dptr(cp), 3, L.dptr(tau), 1, G.GPV_WANT_LOGLIK_Z, L.dptr(s)) == 2
+    mp = G.MultiPlan(pva["locsord"], prep["revNNarray"], prep["revCond"], devices=[0, 0])
+    assert L.lib().gpv_mplan_build_posterior(mp._h, L.iptr(rp._nn), L.iptr(rp._cd)) == 2     # shards cannot run the pass
