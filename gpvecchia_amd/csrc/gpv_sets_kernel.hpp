@@ -69,6 +69,12 @@
 #ifndef GPV_OPT_XYEXT
 #define GPV_OPT_XYEXT 1       // staged coordinates followed by a copy of the first P/2 rows: partner (r+s) never wraps, no select per fetch
 #endif
+#ifndef GPV_OPT_EXECFIX
+#define GPV_OPT_EXECFIX 1     // DPP sweep: the pivot lane's two special writes under a one-lane-per-set EXEC mask (2 VALU) instead of a
+#endif                        // compare and four selects (5 VALU) per pivot
+#ifndef GPV_OPT_FREEZE
+#define GPV_OPT_FREEZE 1      // DPP sweep: row slots whose pivots are all done stop taking part; their last column is completed by a
+#endif                        // block back-substitution after the sweep (P = 31: 14 FMAs instead of 105 + 14 multipliers)
 #ifndef GPV_OPT_RCP3
 #define GPV_OPT_RCP3 1        // pivot reciprocal: one third-order step on the v_rcp_f64 seed (3 FMAs) instead of two Newton steps (4)
 #endif
@@ -162,11 +168,39 @@ __device__ __forceinline__ double set_bcast(double x)
         return dpp_row_bcast<LN % 16>(LN < 16 ? y.lo : y.hi);
     }
 }
+// Inline asm is invisible to hipcc's hazard recogniser: values a following DPP instruction reads from other lanes are
+// passed through here (two wait states behind their VALU writers, which the "+v" constraints order in front)
+__device__ __forceinline__ void dpp_settle(double &x, double &y)
+{
+    asm volatile("s_nop 1" : "+v"(x), "+v"(y));
+}
 // acc += (src of lane N of the DPP row) * w
 template <int N>
 __device__ __forceinline__ void dpp_fmac(double &acc, double src, double w)
 {
     asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w), "n"(N));
+}
+
+// In the lane that owns the pivot row (lane SH of every set; LPS lanes per set): nw = 0 (the pivot row itself is left
+// untouched by its own elimination step) and pr = rinv (the row remembers the reciprocal of its pivot).  Done under an EXEC
+// mask with one lane per set: two VALU instructions and four SALU ones, which issue beside another wave's VALU work, instead
+// of a lane compare and four 32-bit selects.  EXEC is restored before the statement ends; all lanes are live in the sweep
+// (idle lanes run it on dummy rows), the AND only keeps a lane that is not live from being switched on.
+template <int LPS, int SH>
+__device__ __forceinline__ void pivot_lane_fix(double &nw, double &pr, double rinv)
+{
+    static_assert(LPS == 16 || LPS == 32, "DPP geometries");
+    constexpr unsigned M = (LPS == 16 ? 0x00010001u : 0x00000001u) << SH;
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b32 exec_lo, exec_lo, %[m]\n\t"
+                 "s_and_b32 exec_hi, exec_hi, %[m]\n\t"
+                 "v_mov_b64 %[nw], 0\n\t"
+                 "v_mov_b64 %[pr], %[ri]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(sv), [nw] "+v"(nw), [pr] "+v"(pr)
+                 : [m] "n"(M), [ri] "v"(rinv)
+                 : "scc");
 }
 
 template <int P, int D, int COV>
@@ -287,7 +321,7 @@ __device__ __forceinline__ double sqrt_pos(double x)
     // e is taken against the ROUNDED g, which cancels half of g's own rounding error: the result errs by < 1 ulp.
     const double g0 = x * y;
     const double e0 = __builtin_fma(-g0, y, 1.0);
-    const double c0 = fma_vs_half(e0, 0.375);
+    const double c0 = __builtin_fma(e0, 0.375, 0.5);
     return __builtin_fma(g0 * e0, c0, g0);
 #endif
     double g = x * y;
@@ -395,9 +429,12 @@ __device__ __forceinline__ double exp_neg_scaled(double t, const ExpScaled &E)
     double r = __builtin_fma(kd, -6.93147180369123816490e-01, -t);
     r = __builtin_fma(kd, -1.90821492927058770002e-10, r);
 #endif
-    double p = fma_vvs(E.c[0], r, E.c[1]);
+    // plain FMAs on the loop-invariant coefficients (they sit in registers: VOP3 takes three distinct sources, no move per
+    // step).  NOT inline asm: hipcc puts an s_nop between two dependent inline-asm instructions it cannot see into, one
+    // issue slot per Horner step (10 per pair: rounds 1 and 2 of this build paid them)
+    double p = __builtin_fma(E.c[0], r, E.c[1]);
 #pragma unroll
-    for (int i = 2; i < 12; ++i) p = fma_vvs(p, r, E.c[i]);
+    for (int i = 2; i < 12; ++i) p = __builtin_fma(p, r, E.c[i]);
     return __builtin_ldexp(p, __double2loint(kk));
 }
 
@@ -954,23 +991,64 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     pj = dpp_row_bcast<j % 16>((j % 32) < 16 ? ylo[qj] : yhi[qj], ylo[0], yhi[0], ylo[RPL - 1], yhi[RPL - 1]);
                 }
                 const double rinv = rcp_pivot_bounded(pj);
+                // row slots below qj hold only rows whose own pivot step is over.  Gauss-Jordan would go on reducing them
+                // (their last column is the solution); with FREEZE they rest from here on and are completed after the sweep
+                constexpr int Q0 = (GPV_OPT_FREEZE != 0) ? qj : 0;
+                double nw[RPL];
+#if GPV_OPT_EXECFIX
+#pragma unroll
+                for (int q = Q0; q < RPL; ++q) nw[q] = a[q][j] * -rinv;
+                pivot_lane_fix<LPS, j % LPS>(nw[qj], prinv[qj], rinv);
+#else
                 const bool isp = (i == j % LPS);
                 prinv[qj] = isp ? rinv : prinv[qj];
-                double nw[RPL];
 #pragma unroll
-                for (int q = 0; q < RPL; ++q) {
+                for (int q = Q0; q < RPL; ++q) {
                     const double aj = (q == qj && isp) ? 0.0 : a[q][j];   // the pivot row itself is left untouched
                     nw[q] = aj * -rinv;
                 }
+#endif
                 static_for<j + 1, P>([&](auto cc) __attribute__((always_inline)) {
                     constexpr int c = decltype(cc)::value;
 #pragma unroll
-                    for (int q = 0; q < RPL; ++q) {
+                    for (int q = Q0; q < RPL; ++q) {
                         if constexpr (LPS == 16) dpp_fmac<c % 16>(a[q][c], a[c / 16][j], nw[q]);
                         else dpp_fmac<c % 16>(a[q][c], (c % 32) < 16 ? ylo[c / 32] : yhi[c / 32], nw[q]);
                     }
                 });
             });
+            if constexpr (GPV_OPT_FREEZE != 0 && RPL > 1) {
+                // Block back-substitution for the rested slots.  After its own pivots a slot's rows read
+                // [diag(p) | B' | rhs'] over (own columns | later columns | last column), and the solution components of
+                // the later columns c are b_c = a_c[P-1] / p_c, final once every slot behind has been completed:
+                // rhs'_r -= sum_c B'_rc b_c, slot by slot from the last one down.  b_c sits in lane c % LPS of slot c / LPS:
+                // a DPP broadcast inside the FMA, like the sweep's operands.
+                static_for<1, RPL>([&](auto tt) __attribute__((always_inline)) {
+                    constexpr int qs = RPL - decltype(tt)::value;            // RPL-1 .. 1
+                    constexpr int C0 = qs * LPS, C1 = ((qs + 1) * LPS < P - 1) ? (qs + 1) * LPS : P - 1;   // its pivot columns
+                    if constexpr (C1 > C0) {
+                        double nb = -(a[qs][P - 1] * prinv[qs]);            // -b_c in the lane that owns row c
+                        double ylo2 = nb, yhi2 = nb;
+                        if constexpr (LPS == 32) {
+                            const RowPair y = dpp_rowpair(nb);
+                            ylo2 = y.lo;
+                            yhi2 = y.hi;
+                        }
+                        dpp_settle(ylo2, yhi2);                              // VALU write -> DPP read: two wait states
+                        double part[RPL];                                    // odd columns: a second chain per row
+#pragma unroll
+                        for (int q = 0; q < qs; ++q) part[q] = 0.0;
+                        static_for<C0, C1>([&](auto cc) __attribute__((always_inline)) {
+                            constexpr int c = decltype(cc)::value;
+#pragma unroll
+                            for (int q = 0; q < qs; ++q)
+                                dpp_fmac<c % 16>((c & 1) ? part[q] : a[q][P - 1], (LPS == 16 || (c % 32) < 16) ? ylo2 : yhi2, a[q][c]);
+                        });
+#pragma unroll
+                        for (int q = 0; q < qs; ++q) a[q][P - 1] += part[q];
+                    }
+                });
+            }
             vlast = set_bcast<LPS, (P - 1) % LPS>(a[(P - 1) / LPS][P - 1]);
             if constexpr (ZROW) negmu_z = set_bcast<LPS, P % LPS>(a[P / LPS][P - 1]);
         } else {
