@@ -389,12 +389,15 @@ def main():
     def measure_with(plan, flags, denom, steps, warmup, covparms, tau, n):
         """W untimed + K timed evaluations of `plan`; returns (seconds, mean set-kernel ms, loglik)."""
         def step():
-            plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
             if use_dist:
+                plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
                 all_reduce_(sums, dist.ReduceOp.SUM)              # the ONE collective: 64 bytes over xGMI
-            # the 8 sums reach the host every step through a pinned buffer: copy on the launch stream, then wait for
-            # that stream only
-            pinned.copy_(sums, non_blocking=True)
+                # the 8 sums reach the host through a pinned buffer: copy on the launch stream, then poll that stream's event
+                pinned.copy_(sums, non_blocking=True)
+            else:
+                # one GPU: the kernel that totals the sums writes them straight into the pinned host buffer (device-visible
+                # host memory): no copy command between the kernel and the host
+                plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=pinned.data_ptr())
             done.record(tstream)
             while not done.query():                               # spin on the event's flag: no interrupt-driven wake-up
                 pass
@@ -485,16 +488,18 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         rows_rank = b - a
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if os.path.exists(tf) and args.config == "C3" and not custom and world == 1 and args.mode == "L":
-            # HBM bytes per launch from the PMC passes of tools/profile_round.sh; quoted only while the kernel code
-            # they were measured on is the one in this tree
-            try:
-                tj = json.load(open(tf))
-                if tj.get("kernel_code_sha256") == kernel_code_sha256():
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        if args.config == "C3" and not custom and world == 1 and args.mode == "L":
+            # HBM bytes per launch from the PMC passes of tools/profile_round.sh (profiles/rNN_pmc_traffic.json); quoted only
+            # while the kernel code they were measured on is the one in this tree
+            import glob
+            for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+                try:
+                    tj = json.load(open(tf))
+                    if tj.get("kernel_code_sha256") == kernel_code_sha256():
+                        traffic = tj.get("hbm_bytes_per_launch")
+                        break
+                except Exception:
+                    continue
         cond_s = "SGV" if args.mode == "S" else "z"
         ord_s = "maxmin" if args.mode == "S" else "none"
         out = {

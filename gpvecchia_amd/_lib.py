@@ -32,6 +32,7 @@ EXPORTS = [
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
     "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
     "gpv_plan_cache_clear", "gpv_plan_cache_stats", "gpv_plan_vl_begin", "gpv_plan_vl_step", "gpv_plan_vl_get",
+    "gpv_plan_set_user_order", "gpv_plan_vl_begin_user", "gpv_plan_vl_restart", "gpv_plan_vl_get_user", "gpv_plan_vl_loglik",
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
     "gpv_mplan_create_replicas", "gpv_mplan_count", "gpv_mplan_set_data_one", "gpv_mplan_build_posterior",
     "gpv_mplan_eval_each", "gpv_mplan_vl_begin_one", "gpv_mplan_vl_step_each", "gpv_mplan_vl_get_one",
@@ -115,6 +116,11 @@ def lib():
     L.gpv_plan_vl_begin.argtypes = [vp, C.c_int, dp, dp, dp, dp]
     L.gpv_plan_vl_step.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, ip]
     L.gpv_plan_vl_get.argtypes = [vp, dp, dp, dp]
+    L.gpv_plan_set_user_order.argtypes = [vp, ip]
+    L.gpv_plan_vl_begin_user.argtypes = [vp, C.c_int, dp, dp, dp, dp]
+    L.gpv_plan_vl_restart.argtypes = [vp, dp]
+    L.gpv_plan_vl_get_user.argtypes = [vp, dp, dp, dp]
+    L.gpv_plan_vl_loglik.argtypes = [vp, C.c_char_p, dp, C.c_int, dp]
     _lib = L
     return L
 

@@ -292,9 +292,12 @@ struct gpv_plan {
     bool generic = false;          // row length > 64 or dimension > 8: workgroup-per-set kernel (gpv_sets_generic.hip)
     // Vecchia-Laplace state (gpv_plan_vl_begin): data z, prior mean, two latent-mean buffers (current / next), flags + max
     double *d_vl_z = nullptr, *d_vl_pm = nullptr, *d_vl_y[2] = {nullptr, nullptr}, *d_vl_out = nullptr;
+    double *d_vl_y0 = nullptr;                       // the start value, kept so that a restart needs no upload
+    double *d_vl_part = nullptr;                     // scratch of the missing-data and likelihood-term reductions
+    int32_t *d_user_ord = nullptr;                   // ord.z (1-based): caller's layout <-> ordered layout on the device
     int *d_vl_flags = nullptr;
     int vl_model = -1, vl_cur = 0;
-    double vl_alpha = 2.0, vl_sigma = 0.0;
+    double vl_alpha = 2.0, vl_sigma = 0.0, vl_beta = 0.5;
     bool has_z = false, evaluated = false, have_U = false;
     bool timing = true, timed = false;               // hipEvent pair around the set kernel (gpv_plan_set_kernel_timing)
     hipStream_t last_stream = nullptr;
@@ -353,7 +356,8 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
                     pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
-                    pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket};
+                    pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket,
+                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -1088,33 +1092,90 @@ int gpv_plan_get_posterior_mean(gpv_plan *pl, double *mu_ord)
 }
 
 // ---- Vecchia-Laplace Newton-Raphson on the device (R/vecchia_laplace_NR.R:31-155) -------------------------------
-int gpv_plan_vl_begin(gpv_plan *pl, int model, const double *likparms, const double *z_ord, const double *prior_mean_ord,
-                      const double *y_init_ord)
+static int vl_begin_impl(gpv_plan *pl, int model, const double *likparms, const double *z, const double *prior_mean,
+                         const double *y_init, bool user_layout)
 {
-    if (!pl || !z_ord) return GPV_ERR_BAD_ARG;
-    if (!(model == 0 || model == 1 || model == 2 || model == 3 || model == 5)) return GPV_ERR_BAD_ARG;
+    if (!pl || !z) return GPV_ERR_BAD_ARG;
+    if (model < 0 || model > 5) return GPV_ERR_BAD_ARG;
     if (!pl->have_post) return GPV_ERR_STATE;                       // every step is a posterior-mean evaluation
+    if (user_layout && !pl->d_user_ord) return GPV_ERR_STATE;
     GPV_HIP(hipSetDevice(pl->device));
     if (pl->last_stream && pl->last_stream != pl->stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
     const size_t nb = sizeof(double) * (size_t)pl->Nlocs;
-    double **bufs[] = {&pl->d_vl_z, &pl->d_vl_pm, &pl->d_vl_y[0], &pl->d_vl_y[1], &pl->d_nug_user, &pl->d_zuser};
+    double **bufs[] = {&pl->d_vl_z, &pl->d_vl_pm, &pl->d_vl_y[0], &pl->d_vl_y[1], &pl->d_vl_y0, &pl->d_nug_user, &pl->d_zuser};
     for (double **b : bufs)
         if (!*b) GPV_HIP(hipMalloc((void **)b, nb));
     if (pl->dim > 3 && !pl->d_z) GPV_HIP(hipMalloc((void **)&pl->d_z, nb));
-    if (!pl->d_vl_out) GPV_HIP(hipMalloc((void **)&pl->d_vl_out, sizeof(double) * 2));
+    if (!pl->d_vl_out) GPV_HIP(hipMalloc((void **)&pl->d_vl_out, sizeof(double) * 4));
     if (!pl->d_vl_flags) GPV_HIP(hipMalloc((void **)&pl->d_vl_flags, sizeof(int)));
-    GPV_HIP(hipMemcpyAsync(pl->d_vl_z, z_ord, nb, hipMemcpyHostToDevice, pl->stream));
-    if (prior_mean_ord) GPV_HIP(hipMemcpyAsync(pl->d_vl_pm, prior_mean_ord, nb, hipMemcpyHostToDevice, pl->stream));
-    else GPV_HIP(hipMemsetAsync(pl->d_vl_pm, 0, nb, pl->stream));
+    if (!pl->d_vl_part) GPV_HIP(hipMalloc((void **)&pl->d_vl_part, sizeof(double) * 2048));
+    hipStream_t st = pl->stream;
+    // caller's layout: the vector travels as it is and is gathered into the ordering on the device (x_ord[i] = x[ord[i]-1])
+    auto put = [&](const double *src, double *dst) -> int {
+        if (!user_layout) {
+            GPV_HIP(hipMemcpyAsync(dst, src, nb, hipMemcpyHostToDevice, st));
+        } else {
+            GPV_HIP(hipMemcpyAsync(pl->d_stage, src, nb, hipMemcpyHostToDevice, st));
+            GPV_HIP(launch_reorder(pl->d_stage, pl->d_user_ord, pl->Nlocs, dst, true, nullptr, st));
+        }
+        return GPV_OK;
+    };
+    int rc = put(z, pl->d_vl_z);
+    if (rc != GPV_OK) return rc;
+    if (prior_mean) { if ((rc = put(prior_mean, pl->d_vl_pm)) != GPV_OK) return rc; }
+    else GPV_HIP(hipMemsetAsync(pl->d_vl_pm, 0, nb, st));
     // y_init NA -> prior mean (R/vecchia_laplace_NR.R:81-82)
-    if (y_init_ord) GPV_HIP(hipMemcpyAsync(pl->d_vl_y[0], y_init_ord, nb, hipMemcpyHostToDevice, pl->stream));
-    else GPV_HIP(hipMemcpyAsync(pl->d_vl_y[0], pl->d_vl_pm, nb, hipMemcpyDeviceToDevice, pl->stream));
-    GPV_HIP(hipStreamSynchronize(pl->stream));
+    if (y_init) { if ((rc = put(y_init, pl->d_vl_y0)) != GPV_OK) return rc; }
+    else GPV_HIP(hipMemcpyAsync(pl->d_vl_y0, pl->d_vl_pm, nb, hipMemcpyDeviceToDevice, st));
+    GPV_HIP(hipMemcpyAsync(pl->d_vl_y[0], pl->d_vl_y0, nb, hipMemcpyDeviceToDevice, st));
+    GPV_HIP(hipStreamSynchronize(st));
     pl->vl_model = model;
     pl->vl_alpha = likparms ? likparms[0] : 2.0;
     pl->vl_sigma = likparms ? likparms[1] : std::sqrt(0.1);
+    pl->vl_beta = (likparms && model == 4) ? likparms[2] : 0.5;
     pl->vl_cur = 0;
     pl->has_z = true;                                               // the pseudo-data of every step is the plan's data
+    return GPV_OK;
+}
+
+int gpv_plan_vl_begin(gpv_plan *pl, int model, const double *likparms, const double *z_ord, const double *prior_mean_ord,
+                      const double *y_init_ord)
+{
+    return vl_begin_impl(pl, model, likparms, z_ord, prior_mean_ord, y_init_ord, false);
+}
+
+int gpv_plan_set_user_order(gpv_plan *pl, const int *ord_z)
+{
+    if (!pl || !ord_z) return GPV_ERR_BAD_ARG;
+    for (int64_t i = 0; i < pl->Nlocs; ++i)
+        if (ord_z[i] < 1 || (int64_t)ord_z[i] > pl->Nlocs) return GPV_ERR_INDEX;
+    GPV_HIP(hipSetDevice(pl->device));
+    if (!pl->d_user_ord) GPV_HIP(hipMalloc((void **)&pl->d_user_ord, sizeof(int32_t) * (size_t)pl->Nlocs));
+    GPV_HIP(hipMemcpy(pl->d_user_ord, ord_z, sizeof(int32_t) * (size_t)pl->Nlocs, hipMemcpyHostToDevice));
+    return GPV_OK;
+}
+
+int gpv_plan_vl_begin_user(gpv_plan *pl, int model, const double *likparms, const double *z, const double *prior_mean,
+                           const double *y_init)
+{
+    return vl_begin_impl(pl, model, likparms, z, prior_mean, y_init, true);
+}
+
+int gpv_plan_vl_restart(gpv_plan *pl, const double *likparms)
+{
+    // the same data, prior mean and start value as the last gpv_plan_vl_begin*: nothing crosses PCIe
+    if (!pl) return GPV_ERR_BAD_ARG;
+    if (pl->vl_model < 0 || !pl->d_vl_y0) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    if (pl->last_stream && pl->last_stream != pl->stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    GPV_HIP(hipMemcpyAsync(pl->d_vl_y[0], pl->d_vl_y0, sizeof(double) * (size_t)pl->Nlocs, hipMemcpyDeviceToDevice, pl->stream));
+    if (likparms) {
+        pl->vl_alpha = likparms[0];
+        pl->vl_sigma = likparms[1];
+        if (pl->vl_model == 4) pl->vl_beta = likparms[2];
+    }
+    pl->vl_cur = 0;
+    pl->has_z = true;
     return GPV_OK;
 }
 
@@ -1143,13 +1204,17 @@ static int vl_step_enqueue(gpv_plan *pl, const char *covType, const double *covp
     GPV_HIP(hipMemsetAsync(pl->d_vl_flags, 0, sizeof(int), st));
     // pseudo-data and pseudo-nuggets of this step (:93-109) straight into the plan's data / nugget arrays
     double *data_int = pl->dim <= 3 ? pl->d_locs : pl->d_z;
-    GPV_HIP(launch_vl_prepare(pl->vl_model, pl->vl_alpha, pl->vl_sigma, y, pl->d_vl_z, pl->d_vl_pm, pl->Nlocs, pl->d_newpos,
-                              data_int, pl->dim <= 3 ? 4 : 1, pl->dim <= 3 ? 3 : 0, pl->d_zuser, pl->d_nuggets, pl->d_nug_user,
-                              pl->d_vl_flags, st));
+    const int dstr = pl->dim <= 3 ? 4 : 1, doff = pl->dim <= 3 ? 3 : 0;
+    GPV_HIP(launch_vl_prepare(pl->vl_model, pl->vl_alpha, pl->vl_sigma, pl->vl_beta, y, pl->d_vl_z, pl->d_vl_pm, pl->Nlocs,
+                              pl->d_newpos, data_int, dstr, doff, pl->d_zuser, pl->d_nuggets, pl->d_nug_user, pl->d_vl_flags, st));
+    // missing observations: what removeNAs of vecchia_prediction puts in their place (three small kernels that change
+    // nothing when every z is present; a flag read-back to skip them would cost a host round trip per step)
+    GPV_HIP(launch_vl_fill_missing(pl->d_vl_z, pl->Nlocs, pl->d_newpos, data_int, dstr, doff, pl->d_zuser, pl->d_nuggets,
+                                   pl->d_nug_user, pl->d_vl_part, st));
     // vecchia_prediction(pseudo.data, nuggets = D, return.values = 'meanmat') (:112-113)
     const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_MEAN, st, nullptr);
     if (rc != GPV_OK) return rc;
-    GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, st));   // :115-117
+    GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, pl->d_vl_z, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, st));   // :115-117
     return GPV_OK;
 }
 
@@ -1190,6 +1255,64 @@ int gpv_plan_vl_get(gpv_plan *pl, double *mean_ord, double *t_ord, double *D_ord
         for (int64_t i = 0; i < n; ++i) t_ord[i] += pm[(size_t)i];
     }
     if (D_ord) GPV_HIP(hipMemcpy(D_ord, pl->d_nug_user, nb, hipMemcpyDeviceToHost));
+    return GPV_OK;
+}
+
+int gpv_plan_vl_get_user(gpv_plan *pl, double *mean, double *t, double *D)
+{
+    // the same three vectors in the CALLER's layout (x[ord[i]-1] = x_ord[i], scattered on the device); a missing
+    // observation has t = NaN like the reference's pseudo.data (:103-105); D is returned for every location
+    if (!pl) return GPV_ERR_BAD_ARG;
+    if (pl->vl_model < 0 || !pl->have_mean || !pl->d_user_ord) return GPV_ERR_STATE;
+    GPV_HIP(hipSetDevice(pl->device));
+    hipStream_t st = pl->stream;
+    const size_t nb = sizeof(double) * (size_t)pl->Nlocs;
+    double *scratch = pl->d_stage;                                   // [Nlocs]
+    if (mean) {
+        GPV_HIP(launch_reorder(pl->d_mu, pl->d_user_ord, pl->Nlocs, scratch, false, pl->d_vl_pm, st));
+        GPV_HIP(hipMemcpyAsync(mean, scratch, nb, hipMemcpyDeviceToHost, st));
+        GPV_HIP(hipStreamSynchronize(st));
+    }
+    if (t) {
+        GPV_HIP(launch_reorder(pl->d_zuser, pl->d_user_ord, pl->Nlocs, scratch, false, pl->d_vl_pm, st));
+        GPV_HIP(hipMemcpyAsync(t, scratch, nb, hipMemcpyDeviceToHost, st));
+        GPV_HIP(hipStreamSynchronize(st));
+    }
+    if (D) {
+        GPV_HIP(launch_reorder(pl->d_nug_user, pl->d_user_ord, pl->Nlocs, scratch, false, nullptr, st));
+        GPV_HIP(hipMemcpyAsync(D, scratch, nb, hipMemcpyDeviceToHost, st));
+        GPV_HIP(hipStreamSynchronize(st));
+    }
+    return GPV_OK;
+}
+
+int gpv_plan_vl_loglik(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms, double *terms)
+{
+    // vecchia_laplace_likelihood_from_posterior (R/vecchia_laplace_NR.R:376-409) on the state the last Newton step left in
+    // HBM: terms[0] = the pseudo-marginal vecchia_likelihood of the pseudo-data with the pseudo-nuggets (:396-397: one
+    // more evaluation of the plan with the posterior pass; for missing observations the resident values are exactly what
+    // removeNAs substitutes there), terms[1] = model_llh(mean, z) (:402), terms[2] = the pseudo-conditional term (:405).
+    // loglik = terms[0] - terms[2] + terms[1] (:408-409).  Three scalars cross PCIe.
+    if (!pl || !terms) return GPV_ERR_BAD_ARG;
+    if (pl->vl_model < 0 || !pl->have_mean) return GPV_ERR_STATE;
+    CovSetup cs;
+    const int st0 = cov_setup(covType, covparms, ncovparms, cs);
+    if (st0 != GPV_OK) return st0;
+    GPV_HIP(hipSetDevice(pl->device));
+    hipStream_t st = pl->stream;
+    GPV_HIP(launch_vl_terms(pl->vl_model, pl->vl_alpha, pl->vl_sigma, pl->vl_beta, pl->d_vl_y[pl->vl_cur], pl->d_vl_z, pl->d_vl_pm,
+                            pl->d_zuser, pl->d_nug_user, pl->Nlocs, pl->d_vl_part, pl->d_vl_out + 2, st));
+    const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_DENOM, st, nullptr);
+    if (rc != GPV_OK) return rc;
+    double sums[GPV_NSUMS], two[2];
+    GPV_HIP(hipMemcpyAsync(two, pl->d_vl_out + 2, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    const int rc2 = gpv_plan_get_sums(pl, sums);                     // synchronises the stream
+    if (rc2 != GPV_OK) return rc2;
+    double ll = 0.0;
+    gpv_loglik_from_sums(sums, pl->Nlocs, &ll);
+    terms[0] = ll;
+    terms[1] = two[0];
+    terms[2] = two[1];
     return GPV_OK;
 }
 

@@ -17,6 +17,7 @@
 #include "gpv_internal.h"
 #include "gpv_posterior_ext.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace gpv {
 
@@ -87,7 +88,11 @@ __device__ __forceinline__ double post_rcp(const double x)
 // MODE 1 (the columns of the dense top block, gpv_posterior_top_kernel): no epilogue, the partial sums (64 rows, z2, s) go to
 // tpart; the first entries of the row list, up to c1.y, are the other top columns, whose R and t do not exist yet: their
 // B B^T terms and B a are taken here, their R R^T terms and R t are the top kernel's part.
-template <int WPC, int MODE = 0>
+// ZST: the two scalar sums of a column (z2 = sum_c B_kc a_c and s = sum_c R_kc t_c) ride in the LDS tile as two more rows
+// (cnt and cnt + 1) and are totalled by the row-sum step that runs anyway, instead of two 6-step cross-lane butterflies
+// per column (~35 of the ~260 VALU instructions a column cost in the wide levels, which are VALU bound).  Needs
+// cnt + 2 <= 64 row-sum lanes: plans with m + 1 <= 62; longer rows keep the butterflies.
+template <int WPC, int MODE = 0, bool ZST = false>
 __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, const int4 c1, double *T, const int wib,
                                             const int lane, double *tpart = nullptr)
 {
@@ -99,11 +104,13 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     // everything the epilogue needs is requested now, in the same round trip as the row-list records, instead of one
     // more dependent trip after the rounds (the kernel is bound by the number of dependent memory trips per wave)
     const double bk_own = (lane < cnt) ? Ck[1 + lane].x : 0.0;
+    const double ak_own = ZST ? Ck[0].x : 0.0;       // a_k: the column's own term of z2 (B_kk a_k = d_k a_k), wave uniform
     const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
     const double zk = A.z[k];
     const int col = lane >> 2, sub = lane & (kSub - 1);
     // row-sum ownership: up to 32 rows -> two lanes per row (8 columns each), else one lane per row
-    const bool two = A.ld <= 32;
+    const int nrow = ZST ? cnt + 2 : cnt;            // rows of the tile that are summed
+    const bool two = ZST ? (nrow <= 32) : (A.ld <= 32);
     const int srow = two ? (lane & 31) : lane, shalf = two ? (lane >> 5) : 0;
 
     double acc = 0.0, z2 = 0.0, s = 0.0;
@@ -129,18 +136,27 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
             br[u] = Cc[1 + (e < ne ? e : 0)];
         }
         double Bk = 0.0, Rk = 0.0;
+        bool rk_on = false;
         if (act) {
             Bk = own.x;
-            if (sub == 0) z2 = __builtin_fma(Bk, head.x, z2);
+            if (!ZST && sub == 0) z2 = __builtin_fma(Bk, head.x, z2);
             if (ne > 0 && !(MODE == 1 && q < c1.y)) {
                 Rk = own.y;
-                if (sub == 0) s = __builtin_fma(Rk, head.y, s);
+                rk_on = true;
+                if (!ZST && sub == 0) s = __builtin_fma(Rk, head.y, s);
             }
         }
         if (__builtin_amdgcn_ballot_w64(ne > 0) == 0) continue;       // only the column itself in this round (wave uniform)
-        for (int t = lane; t < cnt * kTS; t += 64) T[t] = 0.0;
+        for (int t = lane; t < nrow * kTS; t += 64) T[t] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if constexpr (ZST) {
+            // every pair but the column's own (q == qb, ne == 0: its B_kk a_k is added after the rounds, uniformly)
+            if (sub == 0 && act && q != qb) {
+                T[cnt * kTS + col] = Bk * head.x;
+                T[(cnt + 1) * kTS + col] = rk_on ? Rk * head.y : 0.0;
+            }
+        }
         // entries sub, sub+4, ... of the column: one match byte, one 16-byte (B, R) gather and one LDS store each
         // (0xFF: the row is not in column k (never under SGV) => zero fill; MODE 1, top column: Rk = 0, R_.c = 0)
 #pragma unroll
@@ -161,7 +177,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         __builtin_amdgcn_wave_barrier();
         {
             double r0 = 0.0, r1 = 0.0;                            // fixed association => reproducible
-            if (srow < cnt) {
+            if (srow < nrow) {
                 const double *tr = T + srow * kTS + shalf * 8;
                 if (two) {
                     r0 = (tr[0] + tr[1]) + (tr[2] + tr[3]);
@@ -178,24 +194,32 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (!ZST) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        z2 += __shfl_down(z2, off, 64);
-        s += __shfl_down(s, off, 64);
+        for (int off = 32; off > 0; off >>= 1) {
+            z2 += __shfl_down(z2, off, 64);
+            s += __shfl_down(s, off, 64);
+        }
     }
     if constexpr (WPC > 1) {
         // combine the waves' partial results in wave order (fixed => reproducible)
         __shared__ double part[WPC][66];
         part[wib][lane] = acc;
-        if (lane == 0) { part[wib][64] = z2; part[wib][65] = s; }
+        if (!ZST && lane == 0) { part[wib][64] = z2; part[wib][65] = s; }
         __syncthreads();
         if (wib != 0) return;
         acc = 0.0; z2 = 0.0; s = 0.0;
         for (int v = 0; v < WPC; ++v) {
             acc += part[v][lane];
-            z2 += part[v][64];
-            s += part[v][65];
+            if constexpr (!ZST) {
+                z2 += part[v][64];
+                s += part[v][65];
+            }
         }
+    }
+    if constexpr (ZST) {                                 // rows cnt and cnt + 1 of the tile sums; the column's own term
+        z2 = __builtin_fma(dk, ak_own, __shfl(acc, cnt, 64));
+        s = __shfl(acc, cnt + 1, 64);
     }
     if constexpr (MODE == 1) {
         tpart[lane] = acc;
@@ -217,7 +241,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     }
 }
 
-template <int WPC, int MODE = 0>
+template <int WPC, int MODE = 0, bool ZST = false>
 __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level_kernel(const PostArgs A, int first, int count,
                                                                                         double *toppart, int top_base)
 {
@@ -226,12 +250,12 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     const int wib = threadIdx.x >> 6;
     const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
     if (WPC == 1 && w >= count) return;
-    double *T = tile_all + (size_t)wib * A.ld * kTS;
+    double *T = tile_all + (size_t)wib * (A.ld + 2) * kTS;
     // the structure records are read once per evaluation: non-temporal, so that ~0.3 GB of them per pass do not push the
     // set kernel's index stream and location records out of the Infinity Cache between evaluations
     const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
     const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
-    post_column<WPC, MODE>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
+    post_column<WPC, MODE, ZST>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
 }
 
 // C <- (B, 0) from the row-major Lentries, heads <- (a, 0): one thread per compact entry, coalesced writes
@@ -435,24 +459,35 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
     }
 }
 
+// (GPV_POST_ZST=0 in the environment keeps the cross-lane butterflies: same-box A/B of the tile-row sums)
+static bool zst_enabled(int ld)
+{
+    static const bool off = getenv("GPV_POST_ZST") != nullptr && atoi(getenv("GPV_POST_ZST")) == 0;
+    return !off && ld + 2 <= 64;
+}
+
 // the top block: positions [first, first + K) of the column records hold the columns 0 .. K-1; tpart: [K][66] scratch
 hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, hipStream_t s)
 {
     if (K <= 0) return hipSuccess;
     if (K > kTop) return hipErrorInvalidValue;
-    const size_t smem = (size_t)16 * a.ld * kTS * sizeof(double);
+    const size_t smem = (size_t)16 * (a.ld + 2) * kTS * sizeof(double);
+    const bool zst = zst_enabled(a.ld);
     if (smem > 64 * 1024) {                                   // > 64 KiB of dynamic LDS needs the opt-in, once per device
         static std::atomic<unsigned long long> done{0ull};
         int dev = 0;
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done.load(std::memory_order_relaxed) & bit)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1>),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
             done.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
+    if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, true>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
+    else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, false>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
     hipLaunchKernelGGL(gpv_posterior_top_kernel, dim3(1), dim3(64 * kTopWaves), 0, s, a, (const double *)tpart, K);
     return hipGetLastError();
 }
@@ -465,30 +500,36 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool 
         hipLaunchKernelGGL(gpv_posterior_leaf_kernel, dim3((count + 15) / 16), dim3(256), 0, s, a, first, count);
         return hipGetLastError();
     }
+    const bool zst = zst_enabled(a.ld);
     if (count <= GPV_POST_WIDE16) {                           // narrowest levels: 16 waves per column (all rounds in flight)
-        const size_t smem = (size_t)16 * a.ld * kTS * sizeof(double);
+        const size_t smem = (size_t)16 * (a.ld + 2) * kTS * sizeof(double);
         if (smem > 64 * 1024) {                               // > 64 KiB of dynamic LDS needs the opt-in, once per device
             static std::atomic<unsigned long long> done{0ull};
             int dev = 0;
             (void)hipGetDevice(&dev);
             const unsigned long long bit = 1ull << (dev & 63);
             if (!(done.load(std::memory_order_relaxed) & bit)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0, false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
-        hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
+        if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, true>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
+        else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, false>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
         return hipGetLastError();
     }
     if (count <= GPV_POST_WIDE) {                             // narrow level: the chip is not full anyway, 8 waves per column
-        const size_t smem = (size_t)8 * a.ld * kTS * sizeof(double);
-        hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
+        const size_t smem = (size_t)8 * (a.ld + 2) * kTS * sizeof(double);
+        if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, true>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
+        else hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, false>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
         return hipGetLastError();
     }
     const int wpb = 4;
-    const size_t smem = (size_t)wpb * a.ld * kTS * sizeof(double);
-    hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0);
+    const size_t smem = (size_t)wpb * (a.ld + 2) * kTS * sizeof(double);
+    if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0, true>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0);
+    else hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0, false>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0);
     return hipGetLastError();
 }
 

@@ -75,6 +75,9 @@
 #ifndef GPV_OPT_FREEZE
 #define GPV_OPT_FREEZE 1      // DPP sweep: row slots whose pivots are all done stop taking part; their last column is completed by a
 #endif                        // block back-substitution after the sweep (P = 31: 14 FMAs instead of 105 + 14 multipliers)
+#ifndef GPV_OPT_XYSOA
+#define GPV_OPT_XYSOA 1       // three dimensions: staged coordinates coordinate-major (conflict-free partner reads)
+#endif
 #ifndef GPV_OPT_RCP3
 #define GPV_OPT_RCP3 1        // pivot reciprocal: one third-order step on the v_rcp_f64 seed (3 FMAs) instead of two Newton steps (4)
 #endif
@@ -222,7 +225,14 @@ struct SetsLds {
     // (not for the general-nu variant: there every spare byte of LDS holds rows of the Matern table)
     static constexpr bool XYEXT = GPV_OPT_XYEXT != 0 && D != 0 && COV != COV_DENSE && COV != COV_MATERN_GEN;
     static constexpr int XYROWS = XYEXT ? P + P / 2 : P;
-    double xy[SPW][XYROWS][DS];
+    // D = 3: coordinate-major (x[rows], y[rows], z[rows]).  Row-major rows of 4 doubles put consecutive rows 32 bytes apart:
+    // the rounds' partner reads (lane r reads row r + s) were 2-way (b128) and 4-way (b64) bank conflicts, two thirds of the
+    // LDS-active cycles at P = 61, where ONE wavefront per SIMD hides nothing.  Coordinate-major: consecutive lanes read
+    // consecutive doubles (ds_read2_b64 + ds_read_b64, conflict free).  D = 2 keeps its 16-byte rows (one ds_read_b128).
+    static constexpr bool XYSOA = GPV_OPT_XYSOA != 0 && D == 3 && COV != COV_DENSE;
+    static constexpr int XS_ROW = XYSOA ? 1 : DS, XS_DIM = XYSOA ? XYROWS : 1;   // strides (doubles) of row and coordinate
+    double xy[SPW][XYSOA ? 3 * XYROWS : XYROWS * DS];
+    __device__ __forceinline__ double &xyat(int sub, int row, int t) { return xy[sub][row * XS_ROW + t * XS_DIM]; }
     static constexpr bool NEEDZERO = G::SLOTS > P + (G::ZROW ? 1 : 0);
     double zero[NEEDZERO ? COLS : 2];   // source of the padding rows beyond the data row
     double acc[SPW][kNSums];     // per-set running partial sums
@@ -709,7 +719,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     for (int t = 0; t < A.dim; ++t) {
                         const double c = lp[t];
                         poison[q] = poison[q] | ((c - c) != 0.0);        // NaN or +-Inf
-                        L.xy[sub][row[q]][t] = c;
+                        L.xyat(sub, row[q], t) = c;
                     }
                     if (A.z != nullptr) zi[q] = A.z[idx[q]];
                 } else if constexpr (PFREC) {
@@ -745,12 +755,12 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 }
                 if (lane_on && row[q] < P) {
 #pragma unroll
-                    for (int t = 0; t < D; ++t) L.xy[sub][row[q]][t] = xi[q][t];
+                    for (int t = 0; t < D; ++t) L.xyat(sub, row[q], t) = xi[q][t];
                 }
                 if (Lds::XYEXT && q * LPS < P / 2) {            // rows 0 .. P/2-1 once more behind row P-1 (folds after unrolling)
                     if (lane_on && row[q] < P / 2) {
 #pragma unroll
-                        for (int t = 0; t < D; ++t) L.xy[sub][row[q] + P][t] = xi[q][t];
+                        for (int t = 0; t < D; ++t) L.xyat(sub, row[q] + P, t) = xi[q][t];
                     }
                 }
             }
@@ -793,13 +803,13 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         if constexpr (D == 0) {
                             const int rr = row[q] < P ? row[q] : 0;
                             for (int t = 0; t < A.dim; ++t) {
-                                const double df = L.xy[sub][rr][t] - L.xy[sub][j][t];
+                                const double df = L.xyat(sub, rr, t) - L.xyat(sub, j, t);
                                 r2 += df * df;                   // src/dist.cpp:12-14, left to right from 0.0
                             }
                         } else {
 #pragma unroll
                             for (int t = 0; t < D; ++t) {
-                                const double df = xi[q][t] - L.xy[sub][j][t];
+                                const double df = xi[q][t] - L.xyat(sub, j, t);
                                 r2 = __builtin_fma(df, df, r2);
                             }
                         }
@@ -831,7 +841,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             constexpr int DS = Lds::DS, DD = (D == 0) ? 1 : D;
             // absolute 32-bit LDS byte addresses, the slices' bases folded into the per-lane terms: per pair one select for the
             // partner's coordinates, one add and one select for the triangle slot, the round's constants in the DS offset field
-            const unsigned xy0 = lds_addr(&L.xy[sub][0][0]), tr0 = lds_addr(&L.tri[sub][0]);
+            const unsigned xy0 = lds_addr(&L.xy[sub][0]), tr0 = lds_addr(&L.tri[sub][0]);
             int rq[RPL];
             bool vq[RPL];
             double xq[RPL][DD];
@@ -841,10 +851,10 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const bool own = lane_on && row[q] < P;
                 rq[q] = own ? row[q] : 0;                               // shadows row 0 of the set
 #pragma unroll
-                for (int t = 0; t < D; ++t) xq[q][t] = own ? xi[q][t] : L.xy[sub][0][t];
+                for (int t = 0; t < D; ++t) xq[q][t] = own ? xi[q][t] : L.xyat(sub, 0, t);
                 vq[q] = own ? valid[q] : (bool)((vmask[0] >> (sub * LPS)) & 1ull);
-                xoA[q] = xy0 + __umul24(rq[q], DS * 8);
-                xoB[q] = xoA[q] - P * DS * 8;                           // (used by the lanes with row + s >= P only)
+                xoA[q] = xy0 + __umul24(rq[q], Lds::XS_ROW * 8);
+                xoB[q] = xoA[q] - P * Lds::XS_ROW * 8;                  // (used by the lanes with row + s >= P only)
                 rq8[q] = rq[q] * 8;
                 // slot of the pair (r, r+s), minus 8 s: r+s < P: tri + 8 (rt + r (s+1) + s(s+1)/2 - s), kept incrementally;
                 // wrapped (j = r+s-P < r): tri + 8 (rt + j - s) = tri + 8 (rt + r - P), constant
@@ -853,10 +863,10 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 trB[q] = rt8 + rq8[q] - 8 * P;
             }
             auto fetch = [&](int q, int s, double (&dst)[DD]) {
-                const lds_cdouble *xj = Lds::XYEXT ? lds_ptr(xoA[q] + s * DS * 8)
-                                                   : lds_ptr(((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * DS * 8);
+                const lds_cdouble *xj = Lds::XYEXT ? lds_ptr(xoA[q] + s * Lds::XS_ROW * 8)
+                                                   : lds_ptr(((rq[q] < P - s) ? xoA[q] : xoB[q]) + s * Lds::XS_ROW * 8);
 #pragma unroll
-                for (int t = 0; t < D; ++t) dst[t] = xj[t];
+                for (int t = 0; t < D; ++t) dst[t] = xj[t * Lds::XS_DIM];
             };
             // the partner coordinates of round s+1 are fetched before the values of round s are stored (the compiler
             // cannot move an LDS read above an LDS write on its own), and the RPL pairs of a round are independent

@@ -92,32 +92,51 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
 # ---------------------------------------------------------------------------
 # Newton-Raphson — R/vecchia_laplace_NR.R:31-155
 # ---------------------------------------------------------------------------
-_DEVICE_MODELS = {"gaussian": 0, "logistic": 1, "poisson": 2, "gamma": 3, "gamma_alt": 5}   # position in the list of :32
+_DEVICE_MODELS = {"gaussian": 0, "logistic": 1, "poisson": 2, "gamma": 3, "beta": 4, "gamma_alt": 5}   # position in the list of :32
 
 
-def _posterior_VL_device(z, va, model, covparms, covmodel, likparms, max_iter, convg, y_init, prior_mean, fam, verbose, device):
+def _device_loop_applies(z, va, model, covmodel):
+    return (model in _DEVICE_MODELS and isinstance(covmodel, str) and va["cond_yz"] in ("SGV", "z")
+            and int(np.sum(va["obs"])) == len(z) and va["U_prep"]["revNNarray"].shape[1] <= 64)
+
+
+def _posterior_VL_device(z, va, model, covparms, covmodel, likparms, max_iter, convg, y_init, prior_mean, fam, verbose, device,
+                         want_vectors=True):
     """The loop of R/vecchia_laplace_NR.R:88-130 with y, z, the prior mean, the pseudo-data and the pseudo-nuggets resident
-    in HBM (gpv_plan_vl_begin / gpv_plan_vl_step): per step one elementwise family kernel, the plan's evaluation with vector
-    nuggets (set kernel + posterior pass + mean sweeps) and a max-norm; two scalars come back."""
+    in HBM (gpv_plan_vl_begin_user / gpv_plan_vl_step): per step one elementwise family kernel (all six families; missing
+    observations get removeNAs' substitutes on the device), the plan's evaluation with vector nuggets (set kernel + posterior
+    pass + mean sweeps) and a max-norm; two scalars come back.  The vectors travel in the caller's layout and are reordered
+    on the device; when data, prior mean and start value are the ones already resident (an optimiser over covparms calls
+    this hundreds of times with the same z) nothing is uploaded at all."""
     import ctypes as C
     from . import _lib as L
     plan = A._plan_for(va, device)
     if not plan.has_posterior:
         plan.build_posterior()
-    ordz = va["ord_z"] - 1
-    lp = np.array([float(likparms.get("alpha", 2)), float(likparms.get("sigma", np.sqrt(.1)))])
-    zo = np.ascontiguousarray(z[ordz])
-    pmo = np.ascontiguousarray(prior_mean[ordz])
-    yo = np.ascontiguousarray(y_init[ordz])
+    if not getattr(plan, "_has_user_order", False):
+        ordz = np.ascontiguousarray(va["ord_z"], dtype=np.int32)
+        L.check(L.lib().gpv_plan_set_user_order(plan._h, L.iptr(ordz)), "gpv_plan_set_user_order")
+        plan._has_user_order = True
+    lp = np.array([float(likparms.get("alpha", 2)), float(likparms.get("sigma", np.sqrt(.1))), float(likparms.get("beta", .5))])
     plan.invalidate_data()                               # the loop writes pseudo-data into the plan's data arrays
-    L.check(L.lib().gpv_plan_vl_begin(plan._h, _DEVICE_MODELS[model], L.dptr(lp), L.dptr(zo), L.dptr(pmo), L.dptr(yo)),
-            "gpv_plan_vl_begin")
+    key = getattr(plan, "_vl_key", None)
+    same = (key is not None and key[0] == model and key[1].shape == z.shape and np.array_equal(key[1], z, equal_nan=True)
+            and np.array_equal(key[2], prior_mean) and np.array_equal(key[3], y_init))
+    if same:
+        L.check(L.lib().gpv_plan_vl_restart(plan._h, L.dptr(lp)), "gpv_plan_vl_restart")
+    else:
+        zc, pmc, yc = (np.ascontiguousarray(v, dtype=np.float64) for v in (z, prior_mean, y_init))
+        plan._vl_key = None
+        L.check(L.lib().gpv_plan_vl_begin_user(plan._h, _DEVICE_MODELS[model], L.dptr(lp), L.dptr(zc), L.dptr(pmc), L.dptr(yc)),
+                "gpv_plan_vl_begin_user")
+        plan._vl_key = (model, zc.copy(), pmc.copy(), yc.copy())
     cp = np.ascontiguousarray(covparms, dtype=np.float64)
+    cm = str(covmodel).encode()
     convgd, tot_iters = False, 0
     dmax, flags = C.c_double(), C.c_int()
     for i in range(1, max_iter + 1):                                      # :88
-        L.check(L.lib().gpv_plan_vl_step(plan._h, str(covmodel).encode(), L.dptr(cp), int(cp.size), C.byref(dmax),
-                                         C.byref(flags)), "gpv_plan_vl_step")
+        L.check(L.lib().gpv_plan_vl_step(plan._h, cm, L.dptr(cp), int(cp.size), C.byref(dmax), C.byref(flags)),
+                "gpv_plan_vl_step")
         if flags.value & 1:
             raise ValueError("Negative variances occurred, check parameters")   # :95-98
         if flags.value & 2:
@@ -130,19 +149,25 @@ def _posterior_VL_device(z, va, model, covparms, covmodel, likparms, max_iter, c
             convgd, tot_iters = True, i
             break
         tot_iters += 1
+    out = dict(cnvgd=convgd, iter=tot_iters, data_link=fam["link"], model_llh=fam["llh"], prior_mean=prior_mean,
+               _device_plan=plan)
+    if not want_vectors:
+        return out
     n = len(z)
-    mean_o, t_o, D_o = np.empty(n), np.empty(n), np.empty(n)
-    L.check(L.lib().gpv_plan_vl_get(plan._h, L.dptr(mean_o), L.dptr(t_o), L.dptr(D_o)), "gpv_plan_vl_get")
     mean, t, D = np.empty(n), np.empty(n), np.empty(n)
-    mean[ordz], t[ordz], D[ordz] = mean_o, t_o, D_o                       # back to the caller's order (:135-138)
+    L.check(L.lib().gpv_plan_vl_get_user(plan._h, L.dptr(mean), L.dptr(t), L.dptr(D)), "gpv_plan_vl_get_user")
+    miss = np.isnan(z)
+    if miss.any():                                                        # :103-105: pseudo.data stays NA there, D holds the
+        t[miss] = np.nan                                                  # observed entries only (:100)
+        D = D[~miss]
     preds = dict(mu_obs=mean - prior_mean, mu_pred=np.empty(0), var_obs=None, var_pred=None)
-    return dict(mean=mean, cnvgd=convgd, iter=tot_iters, t=t, D=D, prediction=preds, data_link=fam["link"],
-                model_llh=fam["llh"], prior_mean=prior_mean)
+    out.update(mean=mean, t=t, D=D, prediction=preds)
+    return out
 
 
 def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covparms=None, covmodel="matern",
                            likparms=None, max_iter=50, convg=1e-6, y_init=None, prior_mean=None, verbose=False,
-                           device=0, on_device=None):
+                           device=0, on_device=None, _want_vectors=True):
     z = np.asarray(z, dtype=np.float64)
     likparms = dict(alpha=2, sigma=np.sqrt(.1)) if likparms is None else dict(likparms)
     if covmodel == "matern" and len(covparms) != 3:
@@ -156,13 +181,11 @@ def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covpa
     prior_mean = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64)
     y_o = prior_mean.copy() if y_init is None or np.any(np.isnan(y_init)) else np.asarray(y_init, float).copy()   # :81-82
     va = vecchia_approx
-    if (on_device is not False and likelihood_model in _DEVICE_MODELS and obs_inds.size == len(z) and isinstance(covmodel, str)
-            and va["cond_yz"] in ("SGV", "z") and int(np.sum(va["obs"])) == len(z)
-            and va["U_prep"]["revNNarray"].shape[1] <= 64):
+    if on_device is not False and _device_loop_applies(z, va, likelihood_model, covmodel) and obs_inds.size >= 2:
         return _posterior_VL_device(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, y_o, prior_mean,
-                                    fam, verbose, device)
+                                    fam, verbose, device, want_vectors=_want_vectors)
     if on_device is True:
-        raise ValueError("on_device=True needs fully observed data, a family other than 'beta', cond.yz in {'SGV','z'}")
+        raise ValueError("on_device=True needs cond.yz in {'SGV','z'}, no prediction locations and m + 1 <= 64")
     if len(y_o) > 1:
         y_o = y_o[obs_inds]                                               # :84
     pm_obs = prior_mean[obs_inds]
@@ -229,9 +252,23 @@ def vecchia_laplace_likelihood(z, vecchia_approx, likelihood_model, covparms, li
     """R/vecchia_laplace_NR.R:361-416."""
     z = np.asarray(z, dtype=np.float64)
     post = calculate_posterior_VL(z, vecchia_approx, likelihood_model, covparms, covmodel, likparms, max_iter, convg,
-                                  y_init, prior_mean, device=device)
+                                  y_init, prior_mean, device=device, _want_vectors=False)
     if not post["cnvgd"]:                                                 # :373
         warnings.warn("Convergence Failed, returning -Inf")
         return -np.inf
+    if "_device_plan" in post and "mean" not in post:
+        # the loop ran on the device: the three terms of :376-409 from the state it left there, three scalars come back
+        import ctypes as C
+        from . import _lib as L
+        cp = np.ascontiguousarray(covparms, dtype=np.float64)
+        terms = np.zeros(3)
+        L.check(L.lib().gpv_plan_vl_loglik(post["_device_plan"]._h, str(covmodel).encode(), L.dptr(cp), int(cp.size),
+                                           L.dptr(terms)), "gpv_plan_vl_loglik")
+        ll = terms[0] - terms[2] + terms[1]                               # :408-409
+        if y_init is None:
+            return float(ll)
+        mean = np.empty(len(z))
+        L.check(L.lib().gpv_plan_vl_get_user(post["_device_plan"]._h, L.dptr(mean), None, None), "gpv_plan_vl_get_user")
+        return dict(llv=float(ll), mean=mean)
     return vecchia_laplace_likelihood_from_posterior(z, post, vecchia_approx, likelihood_model, covparms, likparms,
                                                      covmodel, y_init, post["prior_mean"], device=device)

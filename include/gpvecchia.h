@@ -182,7 +182,7 @@ int gpv_plan_get_posterior_mean(gpv_plan *plan, double *mu_ord);
 
 /* Vecchia-Laplace Newton-Raphson with the state on the device: calculate_posterior_VL of R/vecchia_laplace_NR.R:31-155
  * for fully observed data.  model: position in the reference's family list (:32): 0 gaussian, 1 logistic, 2 poisson,
- * 3 gamma, 5 gamma_alt (4 = beta needs digamma: host path of the caller).  likparms = {alpha, sigma} (:33).
+ * 3 gamma, 4 beta, 5 gamma_alt.  likparms = {alpha, sigma} (:33), for beta {alpha, sigma, beta}.
  * z_ord / prior_mean_ord / y_init_ord: ORDERED layout, length Nlocs; prior_mean_ord NULL = 0, y_init_ord NULL = prior
  * mean (:81-82).  Needs gpv_plan_build_posterior.
  * One gpv_plan_vl_step = one pass of the loop body (:91-129): Hessian/score of the family, pseudo-data and
@@ -196,6 +196,25 @@ int gpv_plan_vl_step(gpv_plan *plan, const char *covType, const double *covparms
 /* results of the last step in ordered layout (any pointer may be NULL): posterior mean mu.obs + prior_mean,
  * t = pseudo.data + prior_mean, D (:141-144) */
 int gpv_plan_vl_get(gpv_plan *plan, double *mean_ord, double *t_ord, double *D_ord);
+/* Round 3 additions to the loop above.
+ *   model 4 = beta (R/vecchia_laplace_NR.R:283-295; digamma / trigamma on the device), likparms = {alpha, sigma, beta}.
+ *   Missing observations: z = NaN (:45-46).  Their pseudo-data / pseudo-nuggets are the substitutes removeNAs of
+ *   vecchia_prediction makes (R/vecchia_likelihood.R:45-58: mean and 1e8 x variance of the observed pseudo-data), computed
+ *   on the device every step; the convergence test runs over the observed entries only (:84,:115-117).
+ *   gpv_plan_set_user_order: ord.z of the vecchia.approx (1-based), uploaded once; the *_user entry points then take and
+ *   return vectors in the CALLER's layout and reorder on the device.  In gpv_plan_vl_get_user a missing observation keeps
+ *   the substituted pseudo-data in t (the reference has NA there).
+ *   gpv_plan_vl_restart: the loop again from the start value of the last begin with the data already resident (what an
+ *   optimiser over covparms needs: z, prior mean and start value do not change between its steps); likparms NULL = unchanged.
+ *   gpv_plan_vl_loglik: the three terms of vecchia_laplace_likelihood (R/vecchia_laplace_NR.R:376-409) from the state the
+ *   last step left on the device: terms[0] pseudo-marginal Vecchia likelihood (one more evaluation with the posterior pass),
+ *   terms[1] model_llh(mean, z), terms[2] pseudo-conditional density; loglik = terms[0] - terms[2] + terms[1]. */
+int gpv_plan_set_user_order(gpv_plan *plan, const int *ord_z);
+int gpv_plan_vl_begin_user(gpv_plan *plan, int model, const double *likparms, const double *z, const double *prior_mean,
+                           const double *y_init);
+int gpv_plan_vl_restart(gpv_plan *plan, const double *likparms);
+int gpv_plan_vl_get_user(gpv_plan *plan, double *mean, double *t, double *D);
+int gpv_plan_vl_loglik(gpv_plan *plan, const char *covType, const double *covparms, int ncovparms, double *terms /* 3 */);
 
 /* blocking getters (synchronise the eval's stream first) */
 int gpv_plan_get_sums(gpv_plan *plan, double *sums /* GPV_NSUMS */);

@@ -843,7 +843,7 @@ def test_vecchia_laplace_likelihood(model):
         G.calculate_posterior_VL(np.full(n, -1.0), va, "poisson", cp)      # data outside the support (:52-54)
 
 
-@pytest.mark.parametrize("model", ["poisson", "logistic", "gamma", "gamma_alt", "gaussian"])
+@pytest.mark.parametrize("model", ["poisson", "logistic", "gamma", "gamma_alt", "gaussian", "beta"])
 def test_vecchia_laplace_device_loop_equals_host_loop(model):
     # gpv_plan_vl_begin/step (family arithmetic, pseudo-data and the convergence norm on the device) against the same
     # loop with the family functions in NumPy and one vecchia_prediction per step (the round-1 path, on_device=False)
@@ -861,6 +861,8 @@ def test_vecchia_laplace_device_loop_equals_host_loop(model):
         z = rng.gamma(2.0, np.exp(f) / 2.0)
     elif model == "gamma_alt":
         z = rng.gamma(2.0, 1.0 / np.exp(f))
+    elif model == "beta":                                               # shape parameters beta e^y and beta (:292-293)
+        z = np.clip(rng.beta(0.5 * np.exp(f), 0.5), 1e-6, 1 - 1e-6)
     else:
         z = f + np.sqrt(.1) * rng.standard_normal(n)
     pm = 0.1 * np.cos(3 * locs[:, 0])                                   # a non-trivial prior mean
@@ -868,6 +870,18 @@ def test_vecchia_laplace_device_loop_equals_host_loop(model):
     host = G.calculate_posterior_VL(z, va, model, cp, prior_mean=pm, on_device=False)
     dev = G.calculate_posterior_VL(z, va, model, cp, prior_mean=pm, on_device=True)
     assert dev["cnvgd"] and host["cnvgd"] and dev["iter"] == host["iter"]
+    # the whole likelihood on the device (three scalars back) against the host formula on the host loop's posterior;
+    # a second call finds data, prior mean and start value resident and restarts without an upload
+    ll_host = G.vecchia_laplace_likelihood_from_posterior(z, host, va, model, cp, prior_mean=pm)
+    ll_dev = G.vecchia_laplace_likelihood(z, va, model, cp, prior_mean=pm, convg=1e-6)
+    assert abs(ll_dev - ll_host) <= 1e-9 * abs(ll_host), (ll_dev, ll_host)
+    cp2 = [0.7, 0.13, 1.5]
+    ll2 = G.vecchia_laplace_likelihood(z, va, model, cp2, prior_mean=pm, convg=1e-6)
+    assert ll2 != ll_dev
+    assert G.vecchia_laplace_likelihood(z, va, model, cp, prior_mean=pm, convg=1e-6) == ll_dev     # bitwise: same state, same kernels
+    host2 = G.calculate_posterior_VL(z, va, model, cp2, prior_mean=pm, on_device=False)
+    ll2_host = G.vecchia_laplace_likelihood_from_posterior(z, host2, va, model, cp2, prior_mean=pm)
+    assert abs(ll2 - ll2_host) <= 1e-9 * abs(ll2_host)
     # the two loops differ by the exp of the device library vs NumPy's (<= 1 ulp) fed through a few Newton steps
     np.testing.assert_allclose(dev["mean"], host["mean"], rtol=0, atol=1e-9)
     np.testing.assert_allclose(dev["t"], host["t"], rtol=1e-9, atol=1e-9)

@@ -1,6 +1,6 @@
 """Developer tool: turn the scratch output of tools/profile_round.sh (gpurun_out/<tag>/) into the tracked artefacts under
 profiles/: <name>_bench.json, <name>_kernel_stats.csv, <name>_pmc_pass<i>.csv (set-kernel rows only), <name>_pmc_summary.json
-and r02_pmc_traffic.json (the per-launch HBM traffic bench.py quotes while the kernel source hash matches).
+and <round>_pmc_traffic.json (the per-launch HBM traffic bench.py quotes while the kernel source hash matches).
 
     python tools/collect_profiles.py gpurun_out/r02 r02
     python tools/collect_profiles.py gpurun_out/r02C4 r02_C4 notraffic     (another config: everything but r02_pmc_traffic.json)
@@ -62,6 +62,6 @@ if "FETCH_SIZE" in tot and not (len(sys.argv) > 3 and sys.argv[3] == "notraffic"
                 "kernel in bench.py at n=1e6 m=30 mode L.  Units KB -> x1024; FETCH_SIZE doubled as MI355X_MICROARCH.md "
                 "prescribes for gfx950 (the counter tallies 128-byte fabric requests at 64 bytes); WRITE_SIZE as read.  "
                 "bench.py quotes the figure only while gpv_sets_kernel.hpp, comments and whitespace removed, hashes to kernel_code_sha256.",
-    }, open(os.path.join(P, "r02_pmc_traffic.json"), "w"), indent=1)
+    }, open(os.path.join(P, name.split("_")[0] + "_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(tot.get("_derived", {}), indent=1))
 print(line[:400])
