@@ -21,6 +21,7 @@ GPV_WANT_LOGLIK_Z = 2
 GPV_WANT_NUMERATOR = 4
 GPV_WANT_DENOM = 8
 GPV_WANT_MEAN = 16
+GPV_WANT_MEAN_B = 32
 
 # every symbol include/gpvecchia.h declares (tests check the library exports all of them)
 EXPORTS = [

@@ -270,8 +270,8 @@ struct gpv_plan {
     // the posterior pass as a captured HIP graph (one per {denominator, denominator + mean}): ~140 (280) launches of a few
     // microseconds each, which the host cannot enqueue as fast as the device retires them in the narrow tail levels
     struct PostGraph { hipGraphExec_t exec = nullptr; double *sums_out = nullptr; };
-    PostGraph pgraph[2];
-    double *d_nug_post = nullptr;                    // [Nlocs] nuggets in ordering: fixed kernel argument for the graph
+    PostGraph pgraph[8];                             // index = want_mean + 2 * (nuggets are a vector) + 4 * (mean from B: 'zy')
+    double *d_nug_post = nullptr;                    // ONE double: the constant nugget of the evaluation (PostArgs::nug_cell)
     // general-nu Matern: range of pair distances of the plan (parameter independent) and the per-evaluation table
     double coord_maxabs = 0.0;                       // largest finite |coordinate| (guards the kernel's pre-scaled coordinates)
     double dist_min = 0.0, dist_max = 0.0;
@@ -297,6 +297,8 @@ struct gpv_plan {
     int32_t *d_user_ord = nullptr;                   // ord.z (1-based): caller's layout <-> ordered layout on the device
     int *d_vl_flags = nullptr;
     int vl_model = -1, vl_cur = 0;
+    bool vl_missing = false;                         // some z is NaN: the substitutes of removeNAs are computed every step
+    double *h_vl = nullptr, *h_vl_dev = nullptr;     // pinned: {max|dy|, flags (as a double)} of the step, written by the kernels
     double vl_alpha = 2.0, vl_sigma = 0.0, vl_beta = 0.5;
     bool has_z = false, evaluated = false, have_U = false;
     bool timing = true, timed = false;               // hipEvent pair around the set kernel (gpv_plan_set_kernel_timing)
@@ -367,6 +369,7 @@ int gpv_plan_destroy(gpv_plan *pl)
         if (pl->mt_ev[t]) (void)hipEventDestroy(pl->mt_ev[t]);
     }
     if (pl->h_sums) (void)hipHostFree(pl->h_sums);
+    if (pl->h_vl) (void)hipHostFree(pl->h_vl);
     if (pl->ev0) (void)hipEventDestroy(pl->ev0);
     if (pl->ev1) (void)hipEventDestroy(pl->ev1);
     if (pl->stream) (void)hipStreamDestroy(pl->stream);
@@ -644,7 +647,9 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                           void *stream_v, double *d_sums_out)
 {
     if (flags & GPV_WANT_MEAN) flags |= GPV_WANT_DENOM;
-    if (flags & GPV_WANT_DENOM) {
+    const bool mean_b = (flags & GPV_WANT_MEAN_B) != 0;
+    if (mean_b && (flags & GPV_WANT_DENOM)) return GPV_ERR_BAD_ARG;      // one posterior pass per evaluation
+    if (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) {
         if (!pl->have_post) return GPV_ERR_STATE;
         flags |= GPV_WANT_U | GPV_WANT_NUMERATOR;
     }
@@ -686,13 +691,14 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.z = (flags & (GPV_WANT_LOGLIK_Z | GPV_WANT_NUMERATOR)) ? pl->d_z : nullptr;
     a.covvals = pl->d_covvals;
     a.Lentries = (flags & GPV_WANT_U) ? pl->d_L : nullptr;
-    a.aout = (flags & GPV_WANT_DENOM) ? pl->d_avec : nullptr;
+    a.aout = (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) ? pl->d_avec : nullptr;
     a.block_sums = pl->d_block;
     a.sums = pl->d_sums;
     double *const mirror = d_sums_out ? d_sums_out : pl->h_sums_dev;
     pl->sums_on_host = (d_sums_out == nullptr);
     a.sums_copy = mirror;
     a.ticket = pl->d_ticket;
+    a.nug_cell = (flags & GPV_WANT_DENOM) ? pl->d_nug_post : nullptr;
     a.rows = pl->rows;
     a.nlocs = pl->Nlocs;
     a.locs_ld = pl->locs_ld;
@@ -770,22 +776,34 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         pl->mt_pending = -1;
     }
     // (the partial sums are totalled by the set kernel's last workgroup: no reduction launch)
-    if (flags & GPV_WANT_DENOM) {
-        // nuggets as a vector at a fixed address (scalar: broadcast), so that the pass's kernel arguments never change
-        if (pl->nug_is_scalar) GPV_HIP(launch_fill(pl->d_nug_post, pl->nug_scalar, pl->Nlocs, st));
-        else GPV_HIP(hipMemcpyAsync(pl->d_nug_post, pl->d_nug_user, sizeof(double) * (size_t)pl->Nlocs,
-                                    hipMemcpyDeviceToDevice, st));
+    if (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) {
+        // (constant nugget: the set kernel above left it in d_nug_post[0]; vector: d_nug_user, a fixed address as well)
         PostArgs pa;
         pa.colptr = pl->d_colptr; pa.crow = pl->d_crow;
         pa.colrec = pl->d_colrec; pa.rowrec = pl->d_rowrec; pa.tp = pl->d_tp;
         pa.C = pl->d_C; pa.cboff = pl->d_cboff; pa.z = pl->d_zuser;
-        pa.nuggets = pl->d_nug_post;
-        pa.nug_scalar = 0.0;
+        pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
+        pa.nug_cell = pl->d_nug_post;
         pa.tvec = pl->d_tvec; pa.rdiag = pl->d_rdiag; pa.ld = pl->P;
         const bool want_mean = (flags & GPV_WANT_MEAN) != 0;
+        // cond.yz = 'zy' (R/vecchia_prediction.R:68-70,118-126): V.ord is the reversed latent block B of U itself, no
+        // factorisation.  After createU's removal of the dummy latent variables (R/createU.R:166-171) no latent row has an
+        // entry in an observed column, so z2 = U[latent,] z1 = B a with a = z1[latent columns] = the a_k the set kernel
+        // already produces, and mu = -B^-T B^-1 z2 = -B^-T a: ONE lower-triangular solve, the level-scheduled mean sweep
+        // with R := B (the compaction writes B into both halves) and t := a.
+        if (mean_b) pa.tvec = pl->d_avec;
         auto enqueue = [&]() -> hipError_t {
             hipError_t e = launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot,
-                                                    pl->d_cdel, pl->Nlocs, pl->post_nnz, pl->d_C, st);
+                                                    pl->d_cdel, pl->Nlocs, pl->post_nnz, pl->d_C, mean_b, st);
+            if (mean_b) {
+                if (e == hipSuccess)
+                    e = launch_mean_head(pa, pl->d_order2, pl->d_u, pl->d_levptr2, pl->mean_head_levels, st);
+                for (size_t lv = (size_t)pl->mean_head_levels; e == hipSuccess && lv + 1 < pl->levptr2.size(); ++lv)
+                    e = launch_mean_level(pa, pl->d_order2, pl->d_u, pl->levptr2[lv],
+                                          pl->levptr2[lv + 1] - pl->levptr2[lv], st);
+                if (e == hipSuccess) e = launch_negate(pl->d_u, pl->d_mu, pl->Nlocs, st);
+                return e;
+            }
             for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr.size(); ++lv)
                 e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st);
             if (e == hipSuccess && pl->top_K > 0)
@@ -802,7 +820,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             }
             return e;
         };
-        gpv_plan::PostGraph &g = pl->pgraph[want_mean ? 1 : 0];
+        gpv_plan::PostGraph &g = pl->pgraph[(want_mean ? 1 : 0) + (pl->nug_is_scalar ? 0 : 2) + (mean_b ? 4 : 0)];
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cap);
         static const bool no_graph = getenv("GPV_NO_GRAPH") != nullptr;
@@ -829,7 +847,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             }
         }
         if (!launched) GPV_HIP(enqueue());                               // inside someone else's capture, or graphs off
-        if (want_mean) pl->have_mean = true;
+        if (want_mean || mean_b) pl->have_mean = true;
     }
     pl->evaluated = true;
     pl->have_U = (flags & GPV_WANT_U) != 0;
@@ -1068,7 +1086,7 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
     if (pl->mean_head_levels < 4) pl->mean_head_levels = 0;            // not worth a launch of its own
     const size_t nd = sizeof(double) * (size_t)n;
     if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
-    if (!pl->d_nug_post) GPV_HIP(hipMalloc((void **)&pl->d_nug_post, nd));
+    if (!pl->d_nug_post) GPV_HIP(hipMalloc((void **)&pl->d_nug_post, 64));
     for (auto &g : pl->pgraph)                                         // the schedule may have changed
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (!pl->d_tvec) GPV_HIP(hipMalloc((void **)&pl->d_tvec, nd));
@@ -1109,6 +1127,15 @@ static int vl_begin_impl(gpv_plan *pl, int model, const double *likparms, const 
     if (!pl->d_vl_out) GPV_HIP(hipMalloc((void **)&pl->d_vl_out, sizeof(double) * 4));
     if (!pl->d_vl_flags) GPV_HIP(hipMalloc((void **)&pl->d_vl_flags, sizeof(int)));
     if (!pl->d_vl_part) GPV_HIP(hipMalloc((void **)&pl->d_vl_part, sizeof(double) * 2048));
+    if (!pl->h_vl) {
+        GPV_HIP(hipHostMalloc((void **)&pl->h_vl, sizeof(double) * 8, hipHostMallocDefault));
+        GPV_HIP(hipHostGetDevicePointer((void **)&pl->h_vl_dev, pl->h_vl, 0));
+    }
+    {
+        bool miss = false;
+        for (int64_t i = 0; i < pl->Nlocs && !miss; ++i) miss = (z[i] != z[i]);
+        pl->vl_missing = miss;
+    }
     hipStream_t st = pl->stream;
     // caller's layout: the vector travels as it is and is gathered into the ordering on the device (x_ord[i] = x[ord[i]-1])
     auto put = [&](const double *src, double *dst) -> int {
@@ -1207,14 +1234,16 @@ static int vl_step_enqueue(gpv_plan *pl, const char *covType, const double *covp
     const int dstr = pl->dim <= 3 ? 4 : 1, doff = pl->dim <= 3 ? 3 : 0;
     GPV_HIP(launch_vl_prepare(pl->vl_model, pl->vl_alpha, pl->vl_sigma, pl->vl_beta, y, pl->d_vl_z, pl->d_vl_pm, pl->Nlocs,
                               pl->d_newpos, data_int, dstr, doff, pl->d_zuser, pl->d_nuggets, pl->d_nug_user, pl->d_vl_flags, st));
-    // missing observations: what removeNAs of vecchia_prediction puts in their place (three small kernels that change
-    // nothing when every z is present; a flag read-back to skip them would cost a host round trip per step)
-    GPV_HIP(launch_vl_fill_missing(pl->d_vl_z, pl->Nlocs, pl->d_newpos, data_int, dstr, doff, pl->d_zuser, pl->d_nuggets,
-                                   pl->d_nug_user, pl->d_vl_part, st));
+    // missing observations (seen when the data were uploaded): what removeNAs of vecchia_prediction puts in their place
+    if (pl->vl_missing)
+        GPV_HIP(launch_vl_fill_missing(pl->d_vl_z, pl->Nlocs, pl->d_newpos, data_int, dstr, doff, pl->d_zuser, pl->d_nuggets,
+                                       pl->d_nug_user, pl->d_vl_part, st));
     // vecchia_prediction(pseudo.data, nuggets = D, return.values = 'meanmat') (:112-113)
     const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_MEAN, st, nullptr);
     if (rc != GPV_OK) return rc;
-    GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, pl->d_vl_z, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, st));   // :115-117
+    // :115-117; the step's two scalars (max |dy| and the flag word) land in pinned host memory: no copy command
+    GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, pl->d_vl_z, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, pl->d_vl_flags,
+                             pl->h_vl_dev, st));
     return GPV_OK;
 }
 
@@ -1222,11 +1251,9 @@ static int vl_step_finish(gpv_plan *pl, double *dmax, int *flags)
 {
     GPV_HIP(hipSetDevice(pl->device));
     hipStream_t st = pl->stream;
-    double h_out = 0.0;
-    int h_flags = 0;
-    GPV_HIP(hipMemcpyAsync(&h_out, pl->d_vl_out, sizeof(double), hipMemcpyDeviceToHost, st));
-    GPV_HIP(hipMemcpyAsync(&h_flags, pl->d_vl_flags, sizeof(int), hipMemcpyDeviceToHost, st));
     GPV_HIP(hipStreamSynchronize(st));
+    const double h_out = pl->h_vl[0];
+    const int h_flags = (int)pl->h_vl[1];
     *dmax = h_out;
     *flags = h_flags;
     if (h_out == h_out) pl->vl_cur ^= 1;          // NaN: the reference keeps y_prev (:117-122)

@@ -32,6 +32,7 @@ struct SetArgs {
     double *sums;            // [kNSums] their fixed-order total, written by the workgroup that finishes last (gpv_reduce_tail.hpp)
     double *sums_copy;       // second destination of the totals (the caller's all-reduce buffer) or nullptr
     unsigned *ticket;        // arrival counter of the launch's workgroups; zero between launches
+    double *nug_cell;        // where the posterior pass reads the constant nugget from (PostArgs::nug_cell), or nullptr
     int64_t rows;            // conditioning sets in this launch
     int64_t nlocs;
     int locs_ld;             // doubles per location in `locs`
@@ -91,15 +92,18 @@ struct PostArgs {
     const int32_t *cboff;    // [n] offset of column k's block in C
     const double *z;         // [n] ordered data
     const double *nuggets;   // [n] ordered nuggets or nullptr
-    double nug_scalar;
+    const double *nug_cell;  // constant nugget: ONE double in device memory, written by the set kernel of the same evaluation
+                             // (the pass is replayed as a captured graph: its arguments are frozen, the value is not)
     double *tvec;            // [n] solution of R t = z2
     double *rdiag;           // [n] R_kk (the logarithms are taken by the reduction that sums them)
     int ld;                  // row length of Lentries (bounds the entries per column)
 };
 // C <- (Lentries, a): ccol/cslot give column and Lentries slot of every compact entry
 // cdel[c] = cboff[c] - colptr[c]
+// (both = true: C <- (B, B), for the mean of cond.yz = 'zy' where the factor IS the latent block)
 hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
-                                    const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, hipStream_t s);
+                                    const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, bool both,
+                                    hipStream_t s);
 // columns [first, first+count) of the level-ordered records; leaves = the level's row lists hold the column only (level 0)
 hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, hipStream_t s);
 // posterior mean (R/vecchia_prediction.R:118-126): solve R^T u = t column by column in ASCENDING dependency

@@ -13,9 +13,9 @@ hipError_t launch_vl_prepare(int model, double alpha, double sigma, double beta,
                              const int32_t *newpos, double *data_int, int dstride, int doff, double *data_user,
                              double *nug_int, double *nug_user, int *flags, hipStream_t s);
 // y_new = mu + pm, dmax_out[0] = max |y_new - y_prev| over the OBSERVED entries (z not NaN; NaN if any term is NaN);
-// partial: >= 256 doubles of scratch
+// partial: >= 256 doubles of scratch; host_out (device-visible host memory, or nullptr) receives {dmax, *flags}
 hipError_t launch_vl_update(const double *mu, const double *pm, const double *y_prev, const double *z, double *y_new, int64_t n,
-                            double *partial, double *dmax_out, hipStream_t s);
+                            double *partial, double *dmax_out, const int *flags, double *host_out, hipStream_t s);
 // missing observations (z NaN): launch_vl_prepare leaves NaN pseudo-data there; this replaces them, in both layouts, by what
 // removeNAs of vecchia_prediction substitutes (R/vecchia_likelihood.R:45-58): the mean of the observed pseudo-data and
 // the nugget var(observed pseudo-data) * 1e8.  partial: >= 1024 doubles of scratch

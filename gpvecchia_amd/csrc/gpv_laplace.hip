@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(256) gpv_vl_update_kernel(const double *mu, co
     }
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
-__global__ void __launch_bounds__(64) gpv_vl_max_kernel(const double *partial, int nb, double *out)
+__global__ void __launch_bounds__(64) gpv_vl_max_kernel(const double *partial, int nb, double *out, const int *flags,
+                                                        double *host_out)
 {
     double m = 0.0;
     bool isnan_ = false;
@@ -163,7 +164,14 @@ __global__ void __launch_bounds__(64) gpv_vl_max_kernel(const double *partial, i
         m = o > m ? o : m;
         isnan_ = isnan_ || (on != 0);
     }
-    if (threadIdx.x == 0) out[0] = isnan_ ? __builtin_nan("") : m;
+    if (threadIdx.x == 0) {
+        const double v = isnan_ ? __builtin_nan("") : m;
+        out[0] = v;
+        if (host_out != nullptr) {
+            host_out[0] = v;
+            host_out[1] = (double)flags[0];
+        }
+    }
 }
 
 hipError_t launch_vl_prepare(int model, double alpha, double sigma, double beta, const double *y, const double *z, const double *pm,
@@ -178,12 +186,12 @@ hipError_t launch_vl_prepare(int model, double alpha, double sigma, double beta,
 }
 
 hipError_t launch_vl_update(const double *mu, const double *pm, const double *y_prev, const double *z, double *y_new, int64_t n,
-                            double *partial, double *dmax_out, hipStream_t s)
+                            double *partial, double *dmax_out, const int *flags, double *host_out, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     const int nb = 256;
     hipLaunchKernelGGL(gpv_vl_update_kernel, dim3(nb), dim3(256), 0, s, mu, pm, y_prev, z, y_new, n, partial);
-    hipLaunchKernelGGL(gpv_vl_max_kernel, dim3(1), dim3(64), 0, s, partial, nb, dmax_out);
+    hipLaunchKernelGGL(gpv_vl_max_kernel, dim3(1), dim3(64), 0, s, partial, nb, dmax_out, flags, host_out);
     return hipGetLastError();
 }
 

@@ -105,7 +105,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     // more dependent trip after the rounds (the kernel is bound by the number of dependent memory trips per wave)
     const double bk_own = (lane < cnt) ? Ck[1 + lane].x : 0.0;
     const double ak_own = ZST ? Ck[0].x : 0.0;       // a_k: the column's own term of z2 (B_kk a_k = d_k a_k), wave uniform
-    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
+    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_cell[0];
     const double zk = A.z[k];
     const int col = lane >> 2, sub = lane & (kSub - 1);
     // row-sum ownership: up to 32 rows -> two lanes per row (8 columns each), else one lane per row
@@ -262,21 +262,24 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
 __global__ void __launch_bounds__(256) gpv_posterior_compact_kernel(const double *L, int ld, const double *avec,
                                                                     const int32_t *colptr, const int32_t *ccol,
                                                                     const uint8_t *cslot, const int32_t *cdel, int64_t n,
-                                                                    int64_t nnz, double2 *C)
+                                                                    int64_t nnz, double2 *C, int both)
 {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nnz; g += stride) {
         const int c = ccol[g];
-        C[g + cdel[c] + 1] = make_double2(L[(int64_t)c * ld + cslot[g]], 0.0);
+        const double b = L[(int64_t)c * ld + cslot[g]];
+        C[g + cdel[c] + 1] = make_double2(b, both ? b : 0.0);
     }
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride)
         C[(int64_t)colptr[c] + cdel[c]] = make_double2(avec[c], 0.0);
 }
 hipError_t launch_posterior_compact(const double *L, int ld, const double *avec, const int32_t *colptr, const int32_t *ccol,
-                                    const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, hipStream_t s)
+                                    const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, bool both,
+                                    hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gpv_posterior_compact_kernel, dim3(4096), dim3(256), 0, s, L, ld, avec, colptr, ccol, cslot, cdel, n, nnz, C);
+    hipLaunchKernelGGL(gpv_posterior_compact_kernel, dim3(4096), dim3(256), 0, s, L, ld, avec, colptr, ccol, cslot, cdel, n, nnz, C,
+                       both ? 1 : 0);
     return hipGetLastError();
 }
 
@@ -291,7 +294,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
     const int k = c0.x, cnt = c0.z;
     double2 *Ck = A.C + c0.y;
     const double dk = Ck[cnt].x;
-    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar;
+    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_cell[0];
     const double itau = post_rcp(tau);
     double rkk, rinv;
     top_pivot(__builtin_fma(dk, dk, 0.0) + itau, rkk, rinv);
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
         vb[j] = own ? Ck[1 + lane].x : 0.0;
         vd[j] = own ? Ck[cntj[j]].x : 0.0;
         vp[j] = own ? tpart[66 * (size_t)k + lane] : 0.0;
-        vt[j] = own ? ((A.nuggets != nullptr) ? A.nuggets[k] : A.nug_scalar) : 1.0;
+        vt[j] = own ? ((A.nuggets != nullptr) ? A.nuggets[k] : A.nug_cell[0]) : 1.0;
         const bool last = own && lane == cntj[j] - 1;
         vz[j] = last ? A.z[k] : 0.0;
         vpz[j] = last ? tpart[66 * (size_t)k + 64] : 0.0;

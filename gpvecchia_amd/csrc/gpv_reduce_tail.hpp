@@ -61,7 +61,10 @@ __device__ __forceinline__ void reduce_tail(const SetArgs &A, double mine, doubl
         for (int p2 = 0; p2 < NP; ++p2) t += s_part[p2 * kNSums + threadIdx.x];
         A.sums[threadIdx.x] = t;
         if (A.sums_copy != nullptr) A.sums_copy[threadIdx.x] = t;
-        if (threadIdx.x == 0) *A.ticket = 0u;            // for the next launch (ordered behind this one by its stream)
+        if (threadIdx.x == 0) {
+            *A.ticket = 0u;                              // for the next launch (ordered behind this one by its stream)
+            if (A.nug_cell != nullptr) *A.nug_cell = A.nug_scalar;
+        }
     }
 }
 

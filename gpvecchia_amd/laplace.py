@@ -82,11 +82,54 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         mu = np.empty(n)
         mu[va["ord"] - 1] = plan.posterior_mean()                         # orig.order = order(U.obj$ord), :135-136
         return dict(mu_obs=mu, mu_pred=np.empty(0), var_obs=None, var_pred=None)
+    if (va["cond_yz"] == "zy" and isinstance(covmodel, str) and not np.any(nug == 0)
+            and va["U_prep"]["revNNarray"].shape[1] <= 64):
+        # the reference's default with prediction locations in two or more dimensions (R/vecchia_specify.R:92-96).  V.ord is
+        # the reversed latent block of U (R/vecchia_prediction.R:68-70): set kernel + ONE level-scheduled triangular solve
+        # on the GPU (GPV_WANT_MEAN_B), nothing on the host
+        from ._lib import GPV_WANT_MEAN_B
+        nrows = va["locsord"].shape[0]                                   # n dummy rows + n latent-at-observed + prediction rows
+        plan = A._plan_for(va, device)
+        if not plan.has_posterior:
+            plan.build_posterior()
+        zpad = np.zeros(nrows)
+        zpad[:n] = z[va["ord_z"] - 1]
+        plan.set_data(zpad)
+        nug_all_ord, _, _ = A._ordered_nuggets(va, nug, n)
+        plan.eval(covmodel, covparms, nug_all_ord, GPV_WANT_MEAN_B)
+        mu_ord = plan.posterior_mean()[n:]                               # without the dummy latent variables (R/createU.R:166-171)
+        obs = np.delete(np.asarray(va["obs"], dtype=bool), np.arange(n, 2 * n))
+        mu_obs, mu_pred = A.split_mean(mu_ord, dict(ord=va["ord"], obs=obs))
+        return dict(mu_obs=mu_obs, mu_pred=mu_pred, var_obs=None, var_pred=None)
     U_obj = A.createU(va, covparms, nug, covmodel, device=device)
+    mu_ord = A.vecchia_mean_host(z, U_obj)
     if U_obj["zero_nugg"]:
-        raise NotImplementedError("posterior mean with zero nuggets (R/vecchia_prediction.R:129-132) is not built")
-    mu_obs, mu_pred = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)
+        # for zero nugget, observations are posterior means (R/vecchia_prediction.R:129-132); createU has moved those
+        # locations to the end of ord / obs (R/createU.R:190-191)
+        warnings.warn("Rows/cols of V have been removed for data with zero noise")          # :28-29
+        zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]
+        mu_ord = np.concatenate([mu_ord, zord[U_obj["zero_nugg"]["inds_z"] - 1]])
+    mu_obs, mu_pred = A.split_mean(mu_ord, U_obj)
     return dict(mu_obs=mu_obs, mu_pred=mu_pred, var_obs=None, var_pred=None)
+
+
+def vecchia_laplace_prediction(vl_posterior, vecchia_approx, covparms, pred_mean=0.0, covmodel="matern", device=0):
+    """R/vecchia_laplace_NR.R:523-551, means only (variances are not built): vecchia_prediction with the pseudo-data and
+    pseudo-nuggets of a calculate_posterior_VL result, on a vecchia.approx that may carry prediction locations; the latent
+    means and their images under the family's link function."""
+    z_pseudo = np.asarray(vl_posterior["t"], dtype=np.float64) - vl_posterior["prior_mean"]          # :526
+    nug_pseudo = np.asarray(vl_posterior["D"], dtype=np.float64)                                    # :527
+    if nug_pseudo.size < z_pseudo.size:                                   # missing observations: D holds the observed entries
+        full = np.full(z_pseudo.size, np.nan)
+        full[~np.isnan(z_pseudo)] = nug_pseudo
+        nug_pseudo = full
+    preds = vecchia_prediction(z_pseudo, vecchia_approx, covparms, nug_pseudo, covmodel, device=device)   # :530-531
+    preds["mu_pred"] = preds["mu_pred"] + pred_mean                       # :532
+    preds["mu_obs"] = preds["mu_obs"] + vl_posterior["prior_mean"]        # :533
+    link = vl_posterior["data_link"]
+    preds["data_pred"] = link(preds["mu_pred"])                           # :537
+    preds["data_obs"] = link(preds["mu_obs"])                             # :538
+    return preds
 
 
 # ---------------------------------------------------------------------------

@@ -54,9 +54,16 @@ def _nelder_mead_nash(fn, x0, reltol, maxit, abstol=-np.inf, alpha=1.0, beta=0.5
                     F[j] = f if np.isfinite(f) else _BIG
                     count += 1
             recompute = False
-        lo = int(np.argmin(F))                       # first minimum / maximum, like the running comparisons of the original
-        hi = int(np.argmax(F))
-        fl, fh = F[lo], F[hi]
+        # nmmin's scan: L stays where it is unless a vertex is STRICTLY lower, H starts at L and moves to every strictly
+        # higher vertex in index order (ties keep the earlier choice)
+        fl = fh = F[lo]
+        hi = lo
+        for j in range(n + 1):
+            if j != lo:
+                if F[j] < fl:
+                    lo, fl = j, F[j]
+                if F[j] > fh:
+                    hi, fh = j, F[j]
         if fh <= fl + convtol or fl <= abstol:
             break
         cen = (V.sum(axis=0) - V[hi]) / n
@@ -96,9 +103,8 @@ def _nelder_mead_nash(fn, x0, reltol, maxit, abstol=-np.inf, alpha=1.0, beta=0.5
                     break
         if count > maxit:
             break
-    lo = int(np.argmin(F))
-    if count > maxit:
-        code = 1
+    if count > maxit:                                # (like nmmin, the vertex returned is L of the LAST scan, even when the
+        code = 1                                     #  evaluation limit stopped the search right after a lower one was stored)
     return V[lo].copy(), float(F[lo]), count, code
 
 
@@ -155,3 +161,25 @@ def vecchia_estimate(data, locs, X="missing", m=20, covmodel="matern", theta_ini
               dict(zip(("variance", "range", "smoothness", "nugget"), theta_hat)))
     return dict(z=z, beta_hat=beta_hat, theta_hat=theta_hat, trend=trend, locs=locs, covmodel=covmodel,
                 n_evals=evals[0], neg_loglik=float(res.fun), convergence=conv)
+
+
+def vecchia_pred(vecchia_est, locs_pred, X_pred=None, m=30, device=0, **specify_args):
+    """R/vecchia_wrappers.R:134-161, means only (prediction variances are not built): spatial prediction at new locations
+    from the result of vecchia_estimate.  With prediction locations in two or more dimensions vecchia_specify defaults to
+    cond.yz='zy' (R/vecchia_specify.R:92-96), whose posterior mean is one triangular solve on the GPU."""
+    import warnings
+    from .laplace import vecchia_prediction
+    va = A.vecchia_specify(vecchia_est["locs"], m, locs_pred=np.asarray(locs_pred, dtype=np.float64), **specify_args)   # :137
+    theta_hat = np.asarray(vecchia_est["theta_hat"], dtype=np.float64)                               # :140-143
+    preds = vecchia_prediction(vecchia_est["z"], va, theta_hat[:-1], theta_hat[-1],
+                               covmodel=vecchia_est.get("covmodel", "matern"), device=device)
+    if X_pred is not None:                                                                           # :146-147
+        mu_pred = preds["mu_pred"] + np.asarray(X_pred, dtype=np.float64) @ vecchia_est["beta_hat"]
+    elif vecchia_est["trend"] == "none":                                                             # :148-149
+        mu_pred = preds["mu_pred"]
+    elif vecchia_est["trend"] == "constant":                                                         # :150-151
+        mu_pred = preds["mu_pred"] + vecchia_est["beta_hat"][0]
+    else:                                                                                            # :152-156
+        mu_pred = preds["mu_pred"]
+        warnings.warn("X.pred was not specified, so no trend was added back to the predictions")
+    return dict(mean_pred=mu_pred, var_pred=None)                                                    # :159

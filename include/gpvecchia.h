@@ -52,8 +52,15 @@ enum {
                               (R/vecchia_likelihood.R:85-90); needs gpv_plan_build_posterior; implies WANT_U|WANT_NUMERATOR.
                               Nuggets must be > 0 (+Inf = unobserved is fine): a zero nugget makes W infinite and the sums NaN;
                               the reference removes such rows on the host first (R/createU.R:173-193) */
-    GPV_WANT_MEAN = 16     /* + posterior mean of the latent field in ORDERED layout, mu.ord of R/vecchia_prediction.R:118-126
+    GPV_WANT_MEAN = 16,    /* + posterior mean of the latent field in ORDERED layout, mu.ord of R/vecchia_prediction.R:118-126
                               (two triangular solves with the posterior factor); implies GPV_WANT_DENOM */
+    GPV_WANT_MEAN_B = 32   /* posterior mean for cond.yz='zy' (the reference's default with prediction locations in >= 2-D,
+                              R/vecchia_specify.R:92-96): V.ord is the reversed latent block of U itself, no factorisation
+                              (R/vecchia_prediction.R:68-70); mu.ord = -B^-T a by one level-scheduled triangular solve.  The
+                              plan holds the rows of the 'zy' revNNarray (n dummy rows, n latent-at-observed rows, prediction
+                              rows); data: z_ord for the first n rows, anything (0) for the others; the mean comes back for
+                              every row (the first n, the dummies of R/createU.R:166-171, are to be dropped).  Needs
+                              gpv_plan_build_posterior; not together with GPV_WANT_DENOM / GPV_WANT_MEAN */
 };
 
 /* layout of the 8-double partial-sum vector produced by an eval (summed over the

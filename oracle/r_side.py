@@ -541,8 +541,9 @@ def createU(va, covparms, nuggets, covmodel="matern"):
         keep = np.ones(size, dtype=bool)
         keep[inds_U] = False
         U = U[np.ix_(keep, keep)]                                   # :180
+        inds_z = np.where(np.isin(np.where(~latent)[0], inds_U))[0]               # :183
         inds_locs = np.where(np.isin(np.where(latent)[0], cond_on))[0]            # :184
-        zero_nugg = dict(inds_U=inds_U + 1, inds_locs=inds_locs + 1)
+        zero_nugg = dict(inds_U=inds_U + 1, inds_z=inds_z + 1, inds_locs=inds_locs + 1)
         latent = latent.copy()
         latent[cond_on] = False                                     # :188
         latent = latent[keep]                                       # :189
@@ -703,7 +704,7 @@ def separable_loglik_condz(va, U_entries, z, nuggets):
 # posterior mean and Vecchia-Laplace (R/vecchia_prediction.R, R/vecchia_laplace_NR.R), dense restatements
 # ----------------------------------------------------------------------------
 def vecchia_mean(z, U_obj, V, both=False):
-    """R/vecchia_prediction.R:118-142 (no zero nuggets): mu.obs in original order (and mu.pred with both=True)."""
+    """R/vecchia_prediction.R:118-142: mu.obs in original order (and mu.pred with both=True)."""
     from scipy.linalg import solve_triangular
     U = U_obj["U"]
     latent = U_obj["latent"]
@@ -713,6 +714,9 @@ def vecchia_mean(z, U_obj, V, both=False):
     temp = solve_triangular(V, z2[::-1], lower=True)                   # :124
     mu_rev = -solve_triangular(V.T, temp, lower=False)                 # :125
     mu_ord = mu_rev[::-1]                                              # :126
+    if len(U_obj["zero_nugg"]) > 0:                                    # :129-132 for zero nugget, observations are posterior means
+        obs_zero = zord[U_obj["zero_nugg"]["inds_z"] - 1]
+        mu_ord = np.concatenate([mu_ord, obs_zero])
     orig_order = np.argsort(U_obj["ord"], kind="stable")               # :135
     mu = mu_ord[orig_order]                                            # :136
     obs_orig = np.asarray(U_obj["obs"])[orig_order]                    # :137

@@ -116,3 +116,69 @@ def test_invalid_prediction_specifications():
     assert va["cond_yz"] == "SGV" and va["ord_pred"] == "general"
     va = G.vecchia_specify(locs, 5, locs_pred=lp)                             # 2-D defaults: maxmin, zy, obspred
     assert va["cond_yz"] == "zy" and va["ord_pred"] == "obspred" and va["locsord"].shape[0] == 2 * 80 + 30
+
+
+@pytest.mark.parametrize("cond", ["SGV", "y"])
+def test_posterior_mean_with_zero_nuggets(cond):
+    """R/vecchia_prediction.R:129-132: an observation without noise IS the posterior mean of its latent variable; createU
+    removes those rows from U (R/createU.R:173-193) and vecchia_mean appends the data behind the reordered mean."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(31)
+    n, m = 350, 10
+    locs = rng.random((n, 2))
+    cp = [1.0, 0.25, 1.5]
+    tau = np.where(rng.random(n) < 0.3, 0.0, 0.2)
+    z = np.linalg.cholesky(R.MaternFun(R.rdist(locs), cp) + np.diag(tau) + 1e-10 * np.eye(n)) @ rng.standard_normal(n)
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+    mo_ref = R.vecchia_prediction_mean(z, vb, cp, tau)
+    with pytest.warns(UserWarning, match="zero noise"):
+        pred = G.vecchia_prediction(z, va, cp, tau)
+    np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
+    np.testing.assert_array_equal(pred["mu_obs"][tau == 0], z[tau == 0])
+    assert pred["mu_pred"].size == 0
+
+
+def test_zy_mean_runs_on_the_device_and_wrappers():
+    """cond.yz='zy' is what vecchia_specify picks when prediction locations are given in two dimensions: its posterior mean is
+    one triangular solve with the latent block of U, on the GPU (GPV_WANT_MEAN_B), equal to the host route through
+    createU / U2V / two sparse solves (R/vecchia_prediction.R:68-70,118-142).  vecchia_pred and vecchia_laplace_prediction
+    (R/vecchia_wrappers.R:134-161, R/vecchia_laplace_NR.R:523-551) are thin callers of it."""
+    G = _need_gpu()
+    from gpvecchia_amd import api as A
+    rng = np.random.default_rng(8)
+    n, n_p, m = 2000, 700, 15
+    locs, lp = rng.random((n, 2)), rng.random((n_p, 2))
+    cp, tau = [1.1, 0.15, 1.5], 0.07
+    f = np.sin(5 * locs[:, 0]) * np.cos(4 * locs[:, 1])
+    z = f + np.sqrt(tau) * rng.standard_normal(n)
+    va = G.vecchia_specify(locs, m, locs_pred=lp)
+    assert va["cond_yz"] == "zy"
+    pred = G.vecchia_prediction(z, va, cp, tau)                                   # device: set kernel + one level-scheduled solve
+    U_obj = G.createU(va, cp, tau)
+    mo, mp = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)                  # host: sparse U, two triangular solves
+    np.testing.assert_allclose(pred["mu_obs"], mo, rtol=0, atol=1e-9 * np.abs(mo).max())
+    np.testing.assert_allclose(pred["mu_pred"], mp, rtol=0, atol=1e-9 * np.abs(mo).max())
+    # vector nuggets
+    tv = 0.03 + 0.1 * rng.random(n)
+    pred2 = G.vecchia_prediction(z, va, cp, tv)
+    U2 = G.createU(va, cp, tv)
+    mo2, mp2 = A.split_mean(A.vecchia_mean_host(z, U2), U2)
+    np.testing.assert_allclose(pred2["mu_pred"], mp2, rtol=0, atol=1e-9 * np.abs(mo2).max())
+    # vecchia_pred: constant trend added back
+    est = dict(locs=locs, z=z - z.mean(), theta_hat=np.array(cp + [tau]), beta_hat=np.array([z.mean()]), trend="constant",
+               covmodel="matern")
+    vp = G.vecchia_pred(est, lp, m=m)
+    ref = G.vecchia_prediction(z - z.mean(), va, cp, tau)["mu_pred"] + z.mean()
+    np.testing.assert_allclose(vp["mean_pred"], ref, rtol=0, atol=1e-12)
+    assert np.sqrt(np.mean((vp["mean_pred"] - np.sin(5 * lp[:, 0]) * np.cos(4 * lp[:, 1])) ** 2)) < 0.15
+    # vecchia_laplace_prediction: Poisson counts, prediction of the intensity at new locations
+    zc = rng.poisson(np.exp(f)).astype(float)
+    va0 = G.vecchia_specify(locs, m)
+    post = G.calculate_posterior_VL(zc, va0, "poisson", cp)
+    lpred = G.vecchia_laplace_prediction(post, va, cp)
+    direct = G.vecchia_prediction(post["t"] - post["prior_mean"], va, cp, post["D"])
+    np.testing.assert_allclose(lpred["mu_pred"], direct["mu_pred"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(lpred["data_pred"], np.exp(direct["mu_pred"]), rtol=1e-12)
+    assert np.corrcoef(lpred["mu_pred"], np.sin(5 * lp[:, 0]) * np.cos(4 * lp[:, 1]))[0, 1] > 0.8
