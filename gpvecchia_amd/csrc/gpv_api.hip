@@ -267,6 +267,7 @@ struct gpv_plan {
     double *d_avec = nullptr, *d_tvec = nullptr, *d_rdiag = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
+    std::vector<int> lev_lpc;                        // lanes per column of every level's kernel (16 / 32 / 64), from its row lists
     // the posterior pass as a captured HIP graph (one per {denominator, denominator + mean}): ~140 (280) launches of a few
     // microseconds each, which the host cannot enqueue as fast as the device retires them in the narrow tail levels
     struct PostGraph { hipGraphExec_t exec = nullptr; double *sums_out = nullptr; };
@@ -805,7 +806,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                 return e;
             }
             for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr.size(); ++lv)
-                e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0, st);
+                e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0,
+                                           lv < pl->lev_lpc.size() ? pl->lev_lpc[lv] : 64, st);
             if (e == hipSuccess && pl->top_K > 0)
                 e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, st);
             if (e == hipSuccess)
@@ -1014,6 +1016,22 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
             std::stable_sort(b0, e0, [&](int32_t a, int32_t b) {
                 return rowptr[(size_t)a + 1] - rowptr[(size_t)a] > rowptr[(size_t)b + 1] - rowptr[(size_t)b];
             });
+    }
+    // lanes per column of a level: by the mean length of its row lists (the column itself included): rounds of 4 / 8 / 16
+    // columns.  GPV_POST_LPC=64 (or 16, 32) in the environment forces one form (developer A/B).
+    {
+        const char *force = getenv("GPV_POST_LPC");
+        pl->lev_lpc.assign((size_t)(maxlev + 1), 64);
+        for (int32_t l = 0; l <= maxlev; ++l) {
+            const int32_t b0 = pl->levptr[(size_t)l], e0 = pl->levptr[(size_t)l + 1];
+            if (e0 <= b0) continue;
+            double tot = 0.0;
+            for (int32_t i = b0; i < e0; ++i) tot += rowptr[(size_t)order[(size_t)i] + 1] - rowptr[(size_t)order[(size_t)i]];
+            const double mean = tot / (e0 - b0);
+            int lpc = mean <= 4.5 ? 16 : (mean <= 10.0 ? 32 : 64);
+            if (force) lpc = atoi(force);
+            pl->lev_lpc[(size_t)l] = (lpc == 16 || lpc == 32) ? lpc : 64;
+        }
     }
     std::vector<int4> colrec(2 * (size_t)n), rowrec(nnz);
     for (int64_t i = 0; i < n; ++i) {

@@ -105,7 +105,8 @@ hipError_t launch_posterior_compact(const double *L, int ld, const double *avec,
                                     const uint8_t *cslot, const int32_t *cdel, int64_t n, int64_t nnz, double2 *C, bool both,
                                     hipStream_t s);
 // columns [first, first+count) of the level-ordered records; leaves = the level's row lists hold the column only (level 0)
-hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, hipStream_t s);
+// lanes_per_column: 64 (one wavefront per column) or 16 / 32 for levels whose row lists are short (several columns per wavefront)
+hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, int lanes_per_column, hipStream_t s);
 // posterior mean (R/vecchia_prediction.R:118-126): solve R^T u = t column by column in ASCENDING dependency
 // order (order2), mu_ord = -u
 hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u, int first, int count, hipStream_t s);

@@ -258,6 +258,126 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     post_column<WPC, MODE, ZST>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
 }
 
+// ---- several columns per wavefront ----------------------------------------------------------------------------------
+// In the first levels of the schedule a column's row list is short (level L averages about 2 L columns besides itself,
+// n = 1e5 .. 1e6, m = 30, maxmin + SGV): one wavefront per column with 16 column slots per round leaves 7 of 8 lanes
+// idle, and those levels hold most of the columns (they are VALU bound: every wave pays the whole instruction stream).
+// Here a column gets LPC = 16 or 32 lanes (4 or 2 columns per wavefront): rounds of LPC/4 columns with 4 lanes each, a
+// tile of its own per group, every lane sums the rows l, l + LPC, .. of its group's tile.  Same arithmetic per column and
+// a fixed order of every sum => bitwise reproducible; the order differs from the 64-lane kernel's (results equal to
+// rounding).  The two scalar sums ride in the tile like in the ZST form above (needs m + 1 <= 62).
+template <int LPC>
+__global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const PostArgs A, int first, int count)
+{
+    static_assert(LPC == 16 || LPC == 32, "lanes per column");
+    constexpr int G = 64 / LPC, RCG = LPC / kSub, TSG = RCG + 1, NJ = 64 / LPC;   // groups, columns per round, tile stride, rows per lane
+    constexpr int EC = GPV_POST_EC;
+    extern __shared__ double tile_all[];
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int g = lane / LPC, l = lane % LPC;
+    const int col = l >> 2, sub = l & (kSub - 1);
+    const int wcol = (blockIdx.x * (blockDim.x >> 6) + wib) * G + g;            // this group's column of the level
+    const bool live = wcol < count;
+    double *T = tile_all + ((size_t)wib * G + g) * (A.ld + 2) * TSG;
+    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0))]);
+    const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0)) + 1]);
+    const int k = c0.x, cnt = c0.z, nrow = cnt + 2;
+    const int qb = c0.w, qe = live ? c1.x : c0.w;                               // (a group without a column runs no round)
+    double2 *Ck = A.C + c0.y;
+    const double dk = Ck[cnt].x, ak_own = Ck[0].x;
+    double bk_own[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bk_own[j] = (l + j * LPC < cnt) ? Ck[1 + l + j * LPC].x : 0.0;
+    const double tau = (A.nuggets != nullptr) ? A.nuggets[k] : A.nug_cell[0];
+    const double zk = A.z[k];
+    double acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.0;
+    for (int base = qb; __builtin_amdgcn_ballot_w64(base < qe) != 0; base += RCG) {
+        const int q = base + col;
+        const bool act = q < qe;
+        const int4 rr = nt_load(&A.rowrec[act ? q : qb]);
+        const double2 *Cc = A.C + rr.x;
+        const int ne = act ? (rr.z >> 8) : 0;
+        const int tb = rr.y;
+        const double2 head = Cc[0], own = Cc[1 + (rr.z & 255)];                 // (a_c, t_c), (B_kc, R_kc)
+        int pv[EC];
+        double2 br[EC];
+#pragma unroll
+        for (int u = 0; u < EC; ++u) {
+            const int e = sub + u * kSub;
+            pv[u] = (int)__builtin_nontemporal_load(&A.tp[tb + (e < ne ? e : 0)]);
+            br[u] = Cc[1 + (e < ne ? e : 0)];
+        }
+        const double Bk = act ? own.x : 0.0, Rk = (act && ne > 0) ? own.y : 0.0;
+        if (__builtin_amdgcn_ballot_w64(ne > 0) == 0) continue;                 // only the columns themselves in this round
+        for (int t = l; t < nrow * TSG; t += LPC) T[t] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (sub == 0 && act && q != qb) {
+            T[cnt * TSG + col] = Bk * head.x;
+            T[(cnt + 1) * TSG + col] = (ne > 0) ? Rk * head.y : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < EC; ++u)
+            if (sub + u * kSub < ne && pv[u] != 0xFF) T[pv[u] * TSG + col] = br[u].x * Bk - br[u].y * Rk;
+        for (int e0 = sub + EC * kSub; __builtin_amdgcn_ballot_w64(e0 < ne) != 0; e0 += EC * kSub) {   // longer columns
+#pragma unroll
+            for (int u = 0; u < EC; ++u) {
+                const int e = e0 + u * kSub;
+                pv[u] = (int)__builtin_nontemporal_load(&A.tp[tb + (e < ne ? e : 0)]);
+                br[u] = Cc[1 + (e < ne ? e : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < EC; ++u)
+                if (e0 + u * kSub < ne && pv[u] != 0xFF) T[pv[u] * TSG + col] = br[u].x * Bk - br[u].y * Rk;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int r = l + j * LPC;
+            if (r < nrow) {
+                const double *tr = T + r * TSG;
+                double v;
+                if constexpr (RCG == 4) v = (tr[0] + tr[1]) + (tr[2] + tr[3]);
+                else v = ((tr[0] + tr[1]) + (tr[2] + tr[3])) + ((tr[4] + tr[5]) + (tr[6] + tr[7]));
+                acc[j] += v;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // row r of the sums sits in lane r % LPC (of the group), register r / LPC
+    auto row_value = [&](const int r) -> double {
+        double v = acc[0];
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) v = (r / LPC == j) ? acc[j] : v;
+        return __shfl(v, g * LPC + r % LPC, 64);
+    };
+    const double z2raw = row_value(cnt), sraw = row_value(cnt + 1);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (l + j * LPC < cnt) acc[j] = __builtin_fma(bk_own[j], dk, acc[j]);     // c == k term: B_ik d_k
+    const double itau = post_rcp(tau);
+    const double accd = row_value(cnt - 1) + itau;
+    double rkk, rinv;
+    top_pivot(accd, rkk, rinv);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int r = l + j * LPC;
+        if (r < cnt) Ck[1 + r].y = (r == cnt - 1) ? rkk : top_div(acc[j], rkk, rinv);
+    }
+    if (l == 0) {
+        const double z2 = __builtin_fma(-zk, itau, __builtin_fma(dk, ak_own, z2raw));
+        const double t = top_div(z2 - sraw, rkk, rinv);
+        Ck[0].y = t;
+        A.tvec[k] = t;
+        A.rdiag[k] = rkk;
+    }
+}
+
 // C <- (B, 0) from the row-major Lentries, heads <- (a, 0): one thread per compact entry, coalesced writes
 __global__ void __launch_bounds__(256) gpv_posterior_compact_kernel(const double *L, int ld, const double *avec,
                                                                     const int32_t *colptr, const int32_t *ccol,
@@ -495,7 +615,7 @@ hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpa
     return hipGetLastError();
 }
 
-hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, hipStream_t s)
+hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, int lanes_per_column, hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
     double *const np = nullptr;
@@ -503,8 +623,18 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool 
         hipLaunchKernelGGL(gpv_posterior_leaf_kernel, dim3((count + 15) / 16), dim3(256), 0, s, a, first, count);
         return hipGetLastError();
     }
+    if (lanes_per_column < 64 && zst_enabled(a.ld) && count > GPV_POST_WIDE) {   // short row lists: 4 or 2 columns per wavefront
+        const int wpb = 4, G = 64 / lanes_per_column;
+        const size_t smem = (size_t)wpb * G * (a.ld + 2) * (lanes_per_column / kSub + 1) * sizeof(double);
+        const int grid = (count + wpb * G - 1) / (wpb * G);
+        if (lanes_per_column == 16) hipLaunchKernelGGL((gpv_posterior_level_group_kernel<16>), dim3(grid), dim3(wpb * 64), smem, s, a, first, count);
+        else hipLaunchKernelGGL((gpv_posterior_level_group_kernel<32>), dim3(grid), dim3(wpb * 64), smem, s, a, first, count);
+        return hipGetLastError();
+    }
     const bool zst = zst_enabled(a.ld);
-    if (count <= GPV_POST_WIDE16) {                           // narrowest levels: 16 waves per column (all rounds in flight)
+    static const int wide16 = getenv("GPV_POST_WIDE16") ? atoi(getenv("GPV_POST_WIDE16")) : GPV_POST_WIDE16;
+    static const int wide8 = getenv("GPV_POST_WIDE") ? atoi(getenv("GPV_POST_WIDE")) : GPV_POST_WIDE;
+    if (count <= wide16) {                           // narrowest levels: 16 waves per column (all rounds in flight)
         const size_t smem = (size_t)16 * (a.ld + 2) * kTS * sizeof(double);
         if (smem > 64 * 1024) {                               // > 64 KiB of dynamic LDS needs the opt-in, once per device
             static std::atomic<unsigned long long> done{0ull};
@@ -523,7 +653,7 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool 
         else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, false>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
         return hipGetLastError();
     }
-    if (count <= GPV_POST_WIDE) {                             // narrow level: the chip is not full anyway, 8 waves per column
+    if (count <= wide8) {                                     // narrow level: the chip is not full anyway, 8 waves per column
         const size_t smem = (size_t)8 * (a.ld + 2) * kTS * sizeof(double);
         if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, true>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
         else hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, false>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);

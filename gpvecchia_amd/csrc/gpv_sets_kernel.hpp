@@ -75,6 +75,9 @@
 #ifndef GPV_OPT_FREEZE
 #define GPV_OPT_FREEZE 1      // DPP sweep: row slots whose pivots are all done stop taking part; their last column is completed by a
 #endif                        // block back-substitution after the sweep (P = 31: 14 FMAs instead of 105 + 14 multipliers)
+#ifndef GPV_PFREC_AT
+#define GPV_PFREC_AT(P) ((P) / 2)   // sweep pivot at which the next task's location records are requested
+#endif
 #ifndef GPV_OPT_XYSOA
 #define GPV_OPT_XYSOA 1       // three dimensions: staged coordinates coordinate-major (conflict-free partner reads)
 #endif
@@ -983,7 +986,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             static_for<0, P - 1>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int qj = j / LPS;                                 // the slot that holds pivot row j (in lane j % LPS)
-                if constexpr (PFREC && j == P / 2) load_rec();              // pidx: the NEXT task's indices by now
+                if constexpr (PFREC && j == GPV_PFREC_AT(P)) load_rec();    // pidx: the NEXT task's indices by now
                 double pj;                                                  // pivot = Schur complement d_j^2
                 double ylo[RPL], yhi[RPL];                                  // LPS = 32: column j of the even / odd DPP row
                 if constexpr (LPS == 16) {
