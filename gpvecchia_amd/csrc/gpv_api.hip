@@ -1028,7 +1028,9 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
             double tot = 0.0;
             for (int32_t i = b0; i < e0; ++i) tot += rowptr[(size_t)order[(size_t)i] + 1] - rowptr[(size_t)order[(size_t)i]];
             const double mean = tot / (e0 - b0);
-            int lpc = mean <= 4.5 ? 16 : (mean <= 10.0 ? 32 : 64);
+            static const double t16 = getenv("GPV_POST_T16") ? atof(getenv("GPV_POST_T16")) : 4.5;
+            static const double t32 = getenv("GPV_POST_T32") ? atof(getenv("GPV_POST_T32")) : 10.0;
+            int lpc = mean <= t16 ? 16 : (mean <= t32 ? 32 : 64);
             if (force) lpc = atoi(force);
             pl->lev_lpc[(size_t)l] = (lpc == 16 || lpc == 32) ? lpc : 64;
         }
