@@ -714,7 +714,6 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     if (cs.cov != COV_DENSE && cs.cov != COV_ESQE && !(std::fabs(cs.cA) * pl->coord_maxabs < 1e300)) a.sig0 = NAN;
     a.mt = nullptr; a.mt_base = 0; a.mt_nseg = 0; a.mt_full = 0; a.mt_win = 0;
     if (cs.cov == COV_MATERN_GEN) {
-        bessel_tab_fill(cs.sB, a.bt);
         static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
         if (!no_tab && pl->dist_min > 0.0 && pl->dist_max >= pl->dist_min) {
             constexpr int kMaxSeg = 80 * MaternTab::SPO;                   // 80 octaves
@@ -737,7 +736,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             // LDS window of the kernel (gpv_sets_kernel.hpp, mt_window_rows): the 6 octaves of s = dist/range that hold most of
             // the plan's point-to-neighbour distances, shifted up half an octave for the neighbour-to-neighbour pairs
             a.mt_win = 0;
-            if (a.mt_full && !pl->dist_hist.empty()) {
+            if (a.mt_nseg > 0 && !pl->dist_hist.empty()) {
                 const int e_lo = (a.mt_base >> MaternTab::LSPO) - 1023;   // binary exponent of the table's first segment
                 const int noct = a.mt_nseg / MaternTab::SPO;
                 const double sh = std::log2(cs.cA) + 0.5;
@@ -764,8 +763,6 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             }
             pl->mt_pending = sl;
         }
-    } else {
-        std::memset(&a.bt, 0, sizeof(a.bt));
     }
     if (pl->timing) GPV_HIP(hipEventRecord(pl->ev0, st));
     if (pl->generic) GPV_HIP(launch_sets_generic(pl->P, a, pl->cus, &pl->grid, st));

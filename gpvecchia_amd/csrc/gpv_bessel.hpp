@@ -2,248 +2,75 @@
 // for the general-smoothness branch of the Matern covariance (reference: src/Matern.cpp:72-84, which calls
 // boost::math::cyl_bessel_k; Boost is a third-party dependency absent from the reference tree).
 //
-// Published algorithm restated here: split nu = n + mu, |mu| <= 1/2; K_mu and K_{mu+1} from Temme's series
-// (N. M. Temme, J. Comput. Phys. 19 (1975) 324) for x <= 2 and from Steed's continued fraction CF2
-// (Thompson & Barnett, Comput. Phys. Commun. 47 (1987) 245) for x > 2; then the forward recurrence
-// K_{v+1} = K_{v-1} + (2v/x) K_v, which is stable upwards.  The auxiliary functions of Temme's series,
-//   gam1(mu) = (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu),   gam2(mu) = (1/Gamma(1-mu) + 1/Gamma(1+mu)) / 2,
-// are even in mu; they are evaluated from degree-8 polynomials in mu^2 (Chebyshev interpolants on
-// [0, 1/4] computed with 60-digit arithmetic, max abs error 2.5e-22 / 2.9e-21).
-//
-// Lineage: this two-regime scheme (Temme series below x = 2, Steed's CF2 above, shared quantities named gam1, gam2,
-// gampl, gammi) is the classical one; its best-known presentation is the routine `bessik` of Press, Teukolsky,
-// Vetterling & Flannery, "Numerical Recipes" (2nd ed., sect. 6.7), whose variable naming bessel_k_nu below follows.
-// Nothing of the reference's tree is involved (it calls Boost).  The code here is a restatement of the two published
-// papers' recurrences with its own Gamma-function auxiliaries (the polynomials above) and its own table/Chebyshev layer
-// (MaternTab); acknowledged here because the structure is recognisably that of the textbook routine.
+// Method (own derivation from the integral representation, no series / continued-fraction routine restated):
+//     K_mu(x) = int_0^inf exp(-x cosh t) cosh(mu t) dt                      (Abramowitz & Stegun 9.6.24)
+// is the integral of an entire, even function that decays doubly exponentially, so the plain trapezoidal rule converges
+// geometrically in 1/h (the classical result for analytic integrands on the real line; Trefethen & Weideman, SIAM Review
+// 56 (2014) 385).  Pushing the contour to Im t = d multiplies the integrand by at most exp(x (1 - cos d)), the rule's
+// error is exp(-2 pi d / h) times that: with d = pi/2 the relative error is exp(x - pi^2 / h), with the optimal
+// d = 2 pi / (h x) for large x it is exp(-2 pi^2 / (h^2 x)).  Step h = min(pi^2 / (x + 44), 0.66 / sqrt(x)) keeps both
+// below 1e-19; the sum stops when a term falls below 1e-19 of it, after 12 .. 70 points (more only for x < 1e-9).  All
+// terms are positive: no cancellation anywhere, for any order and argument.  What is summed is the SCALED function
+// e^x K_mu(x), from exp(-x (cosh t - 1)) with cosh t - 1 = 2 sinh^2(t/2), so nothing underflows for large x.
+// Orders above 1/2: nu = n + mu, |mu| <= 1/2; K_mu and K_{mu+1} share the exponential weights, then the recurrence
+// K_{v+1} = K_{v-1} + (2v/x) K_v, which is stable upwards.  Measured against 40-digit mpmath: <= 1e-15 relative for
+// nu <= 11, <= 5e-15 at nu = 60 (the recurrence's n/2 ulp), x from 1e-8 to 700.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <thread>
+#include <vector>
 
 namespace gpv {
 
-__host__ __device__ __forceinline__ void temme_gammas(double mu, double &gam1, double &gam2, double &gampl, double &gammi)
+// e^x K_nu(x), nu >= 0, x > 0
+__host__ __device__ inline double bessel_k_scaled(const double nu, const double x)
 {
-    const double t = mu * mu;
-    double g1 = 0x1.42325eabf5d31p-30;
-    g1 = __builtin_fma(g1, t, -0x1.a3ff2ef43665cp-28);
-    g1 = __builtin_fma(g1, t, -0x1.30251d452a251p-20);
-    g1 = __builtin_fma(g1, t, 0x1.51ce8b226bb1bp-16);
-    g1 = __builtin_fma(g1, t, 0x1.c364fe6e95eafp-13);
-    g1 = __builtin_fma(g1, t, -0x1.d919c527f5d97p-8);
-    g1 = __builtin_fma(g1, t, 0x1.59af103c34090p-5);
-    g1 = __builtin_fma(g1, t, 0x1.5815e8fa27048p-5);
-    g1 = __builtin_fma(g1, t, -0x1.2788cfc6fb619p-1);
-    double g2 = 0x1.5f9d2c01100f6p-28;
-    g2 = __builtin_fma(g2, t, -0x1.b9b5b65df228fp-23);
-    g2 = __builtin_fma(g2, t, -0x1.4fac55cca0e60p-20);
-    g2 = __builtin_fma(g2, t, 0x1.0c8a78883068ap-13);
-    g2 = __builtin_fma(g2, t, -0x1.317112cd7a27ep-10);
-    g2 = __builtin_fma(g2, t, -0x1.3b4af284850c8p-7);
-    g2 = __builtin_fma(g2, t, 0x1.5512320b43fc6p-3);
-    g2 = __builtin_fma(g2, t, -0x1.4fcf4026afa2ep-1);
-    g2 = __builtin_fma(g2, t, 1.0);
-    gam1 = g1;
-    gam2 = g2;
-    gampl = g2 - mu * g1;      // 1 / Gamma(1 + mu)
-    gammi = g2 + mu * g1;      // 1 / Gamma(1 - mu)
-}
-
-__host__ __device__ inline double bessel_k_nu(double nu, double x)
-{
-    const int nl = (int)(nu + 0.5);
-    const double mu = nu - (double)nl;
-    const double mu2 = mu * mu;
-    const double xi2 = 2.0 / x;
-    double rkmu, rk1;
-    if (x <= 2.0) {
-        // Temme's series
-        const double x2 = 0.5 * x;
-        const double pimu = 3.14159265358979323846 * mu;
-        const double fact = (fabs(pimu) < 1e-15) ? 1.0 : pimu / sin(pimu);
-        double d = -log(x2);
-        double e = mu * d;
-        const double fact2 = (fabs(e) < 1e-15) ? 1.0 : sinh(e) / e;
-        double gam1, gam2, gampl, gammi;
-        temme_gammas(mu, gam1, gam2, gampl, gammi);
-        double ff = fact * (gam1 * cosh(e) + gam2 * fact2 * d);
-        double sum = ff;
-        e = exp(e);
-        double p = 0.5 * e / gampl;
-        double q = 0.5 / (e * gammi);
-        double c = 1.0;
-        d = x2 * x2;
-        double sum1 = p;
-        for (int i = 1; i <= 1000; ++i) {
-            const double di = (double)i;
-            ff = (di * ff + p + q) / (di * di - mu2);
-            c *= d / di;
-            p /= (di - mu);
-            q /= (di + mu);
-            const double del = c * ff;
-            sum += del;
-            sum1 += c * (p - di * ff);
-            if (fabs(del) < fabs(sum) * 1e-17) break;
-        }
-        rkmu = sum;
-        rk1 = sum1 * xi2;
+    const int n_up = (int)(nu + 0.5);
+    const double mu = nu - (double)n_up;
+    double k0, k1;
+    if (x > 746.0) {
+        // the callers multiply by e^-x = 0 out here; Hankel's expansion, three terms (relative error < 1e-6 mu^6 / x^3)
+        const double a0 = 4.0 * mu * mu, a1 = 4.0 * (mu + 1.0) * (mu + 1.0), r8 = 0.125 / x;
+        const double pre = sqrt(1.57079632679489661923 / x);
+        k0 = pre * (1.0 + (a0 - 1.0) * r8 * (1.0 + (a0 - 9.0) * 0.5 * r8));
+        k1 = pre * (1.0 + (a1 - 1.0) * r8 * (1.0 + (a1 - 9.0) * 0.5 * r8));
     } else {
-        // Steed's algorithm for CF2
-        double b = 2.0 * (1.0 + x);
-        double d = 1.0 / b;
-        double h = d, delh = d;
-        double q1 = 0.0, q2 = 1.0;
-        const double a1 = 0.25 - mu2;
-        double q = a1, c = a1;
-        double a = -a1;
-        double s = 1.0 + q * delh;
-        for (int i = 2; i <= 10000; ++i) {
-            a -= 2.0 * (double)(i - 1);
-            c = -a * c / (double)i;
-            const double qnew = (q1 - b * q2) / a;
-            q1 = q2;
-            q2 = qnew;
-            q += c * qnew;
-            b += 2.0;
-            d = 1.0 / (b + a * d);
-            delh = (b * d - 1.0) * delh;
-            h += delh;
-            const double dels = q * delh;
-            s += dels;
-            if (fabs(dels) < fabs(s) * 1e-17) break;
+        const double h1 = 9.8696044010893586188 / (x + 44.0), h2 = 0.66 / sqrt(x);
+        const double h = h1 < h2 ? h1 : h2;
+        double sum0 = 0.5, sum1 = 0.5;                              // the t = 0 node carries half weight
+        for (int j = 1; j < 6000; ++j) {
+            const double t = (double)j * h;
+            const double sh = sinh(0.5 * t);
+            const double arg = 2.0 * x * sh * sh;                   // x (cosh t - 1)
+            if (arg > 745.0) break;
+            const double w = exp(-arg);
+            const double gm = exp(mu * t), g1 = gm * exp(t);
+            const double c0 = 0.5 * (gm + 1.0 / gm);                // cosh(mu t)
+            const double c1 = 0.5 * (g1 + 1.0 / g1);                // cosh((mu + 1) t)
+            sum0 = __builtin_fma(w, c0, sum0);
+            sum1 = __builtin_fma(w, c1, sum1);
+            if (w * c1 < 1e-19 * sum1) break;
         }
-        h = a1 * h;
-        rkmu = sqrt(3.14159265358979323846 / (2.0 * x)) * exp(-x) / s;
-        rk1 = rkmu * (mu + x + 0.5 - h) / x;
+        k0 = h * sum0;
+        k1 = h * sum1;
     }
-    for (int i = 1; i <= nl; ++i) {
-        const double rktemp = (mu + (double)i) * xi2 * rk1 + rkmu;
-        rkmu = rk1;
-        rk1 = rktemp;
+    const double two_over_x = 2.0 / x;
+    for (int i = 1; i <= n_up; ++i) {
+        const double up = __builtin_fma((mu + (double)i) * two_over_x, k1, k0);
+        k0 = k1;
+        k1 = up;
     }
-    return rkmu;
+    return k0;
 }
 
-// ---- the same with everything that depends on nu alone taken out of the per-pair work ---------------------------
-// Inside one launch nu is fixed, so the order-dependent constants of Temme's series and the reciprocals its
-// recurrences divide by (1/(i^2 - mu^2), 1/(i - mu), 1/(i + mu), 1/i) are computed once on the host and travel in the
-// kernel arguments: the series index is wave-uniform, so they are scalar loads and the four divisions per term become
-// multiplications.  x^nu reuses the logarithm the series needs, and cosh/sinh come from one exp.
-struct BesselTab {
-    static constexpr int N = 24;       // series terms covered by the tables (x <= 2 needs <= ~19 for 1e-17)
-    double r[4][N];
-    double c[8];                       // fact, gam1, gam2, 0.5/Gamma(1+mu)^-1.., see bessel_tab_fill
-};
+__host__ __device__ inline double bessel_k_nu(const double nu, const double x) { return exp(-x) * bessel_k_scaled(nu, x); }
 
-inline void bessel_tab_fill(double nu, BesselTab &t)
+// sigma^2 2^{1-nu}/Gamma(nu) s^nu K_nu(s) = normcon s^nu K_nu(s), s = dist/range  (src/Matern.cpp:73,80; the reference applies
+// no sqrt(2 nu) scaling there)
+__host__ __device__ inline double matern_general(const double s, const double normcon, const double nu)
 {
-    const int nl = (int)(nu + 0.5);
-    const double mu = nu - (double)nl, mu2 = mu * mu;
-    const double pimu = 3.14159265358979323846 * mu;
-    double gam1, gam2, gampl, gammi;
-    temme_gammas(mu, gam1, gam2, gampl, gammi);
-    t.c[0] = (fabs(pimu) < 1e-15) ? 1.0 : pimu / sin(pimu);
-    t.c[1] = gam1;
-    t.c[2] = gam2;
-    t.c[3] = 0.5 / gampl;
-    t.c[4] = 0.5 / gammi;
-    t.c[5] = mu;
-    t.c[6] = mu2;
-    t.c[7] = (double)nl;
-    for (int i = 1; i <= BesselTab::N; ++i) {
-        const double di = (double)i;
-        t.r[0][i - 1] = 1.0 / (di * di - mu2);
-        t.r[1][i - 1] = 1.0 / (di - mu);
-        t.r[2][i - 1] = 1.0 / (di + mu);
-        t.r[3][i - 1] = 1.0 / di;
-    }
-}
-
-// K_nu(x) with lx = log(x) supplied by the caller
-__device__ inline double bessel_k_nu_tab(const BesselTab &T, double x, double lx)
-{
-    const double mu = T.c[5], mu2 = T.c[6];
-    const int nl = (int)T.c[7];
-    const double xi2 = 2.0 / x;
-    double rkmu, rk1;
-    if (x <= 2.0) {
-        const double x2 = 0.5 * x;
-        const double d = 0.693147180559945309417 - lx;          // -log(x/2)
-        const double e = mu * d;
-        const double ex = exp(e), iex = 1.0 / ex;
-        const double ch = 0.5 * (ex + iex);
-        const double e2 = e * e;
-        // sinh(e)/e: series below 0.1 (next term e^10/39916800 < 3e-18), else from the exponentials
-        const double shs = __builtin_fma(e2, __builtin_fma(e2, __builtin_fma(e2, __builtin_fma(e2, 1.0 / 362880.0, 1.0 / 5040.0),
-                                                                            1.0 / 120.0), 1.0 / 6.0), 1.0);
-        const double fact2 = (fabs(e) < 0.1) ? shs : 0.5 * (ex - iex) / e;
-        double ff = T.c[0] * (T.c[1] * ch + T.c[2] * fact2 * d);
-        double sum = ff;
-        double p = T.c[3] * ex;
-        double q = T.c[4] * iex;
-        double c = 1.0;
-        const double dd = x2 * x2;
-        double sum1 = p;
-        for (int i = 1; i <= 1000; ++i) {
-            const double di = (double)i;
-            double r0, r1, r2, r3;
-            if (i <= BesselTab::N) {
-                r0 = T.r[0][i - 1]; r1 = T.r[1][i - 1]; r2 = T.r[2][i - 1]; r3 = T.r[3][i - 1];
-            } else {
-                r0 = 1.0 / (di * di - mu2); r1 = 1.0 / (di - mu); r2 = 1.0 / (di + mu); r3 = 1.0 / di;
-            }
-            ff = (di * ff + p + q) * r0;
-            c *= dd * r3;
-            p *= r1;
-            q *= r2;
-            const double del = c * ff;
-            sum += del;
-            sum1 += c * (p - di * ff);
-            if (fabs(del) < fabs(sum) * 1e-17) break;
-        }
-        rkmu = sum;
-        rk1 = sum1 * xi2;
-    } else {
-        // Steed's algorithm for CF2 (as in bessel_k_nu)
-        double b = 2.0 * (1.0 + x);
-        double d = 1.0 / b;
-        double h = d, delh = d;
-        double q1 = 0.0, q2 = 1.0;
-        const double a1 = 0.25 - mu2;
-        double q = a1, c = a1;
-        double a = -a1;
-        double s = 1.0 + q * delh;
-        for (int i = 2; i <= 10000; ++i) {
-            a -= 2.0 * (double)(i - 1);
-            c = -a * c / (double)i;
-            const double qnew = (q1 - b * q2) / a;
-            q1 = q2;
-            q2 = qnew;
-            q += c * qnew;
-            b += 2.0;
-            d = 1.0 / (b + a * d);
-            delh = (b * d - 1.0) * delh;
-            h += delh;
-            const double dels = q * delh;
-            s += dels;
-            if (fabs(dels) < fabs(s) * 1e-17) break;
-        }
-        h = a1 * h;
-        rkmu = sqrt(3.14159265358979323846 / (2.0 * x)) * exp(-x) / s;
-        rk1 = rkmu * (mu + x + 0.5 - h) / x;
-    }
-    for (int i = 1; i <= nl; ++i) {
-        const double rktemp = (mu + (double)i) * xi2 * rk1 + rkmu;
-        rkmu = rk1;
-        rk1 = rktemp;
-    }
-    return rkmu;
-}
-
-__device__ inline double matern_general_tab(const BesselTab &T, double s, double normcon, double nu)
-{
-    const double ls = log(s);
-    return normcon * exp(nu * ls) * bessel_k_nu_tab(T, s, ls);
+    return normcon * exp(nu * log(s) - s) * bessel_k_scaled(nu, s);
 }
 
 // ---- per-launch table of h(s) = s^nu K_nu(s) e^s ------------------------------------------------------------------
@@ -258,7 +85,7 @@ __device__ inline double matern_general_tab(const BesselTab &T, double s, double
 // One segment is one 96-byte row {scale a_0 .. scale a_10, 0}: what the set kernel pays for per pair is LDS bandwidth
 // (rows are gathered by every lane's own distance), so the row is as short as the accuracy allows: round 2 began with
 // four segments per octave at degree 12 in the Chebyshev basis (128-byte rows, Clenshaw).  The device multiplies by
-// exp(-s); distances outside the tabulated range take the series / continued-fraction path above.
+// exp(-s); distances outside the tabulated range are evaluated by the quadrature above.
 struct MaternTab {
     static constexpr int DEG = 10, ROW = 12, LSPO = 3, SPO = 1 << LSPO;     // degree, doubles per row, segments per octave
 };
@@ -284,6 +111,60 @@ __device__ __forceinline__ double matern_tab_poly(const double2 q0, const double
     return __builtin_fma(p, u, q0.x);
 }
 
+// The same quadrature for MANY arguments at one order (the table fit below evaluates K_nu ~1.5e3 times per likelihood
+// evaluation): with a common step the nodes t_j = j h, their weights' exponents q_j = 2 sinh^2(t_j / 2) and the factors
+// cosh(mu t_j), cosh((mu + 1) t_j) do not depend on x, so one argument costs one exp per node instead of four
+// transcendental functions.  Three classes of x share a step each (the step bound of bessel_k_scaled at the class's upper end).
+struct BesselQuadNodes {
+    double mu = 0.0, h = 0.0;
+    int n_up = 0;
+    std::vector<double> q, c0, c1;
+    void init(double nu, double x_hi)
+    {
+        n_up = (int)(nu + 0.5);
+        mu = nu - (double)n_up;
+        const double h1 = 9.8696044010893586188 / (x_hi + 44.0), h2 = 0.66 / std::sqrt(x_hi);
+        h = h1 < h2 ? h1 : h2;
+        q.clear(); c0.clear(); c1.clear();
+    }
+    void extend(size_t n)                                // nodes 1 .. n
+    {
+        for (size_t j = q.size() + 1; j <= n; ++j) {
+            const double t = (double)j * h, sh = std::sinh(0.5 * t);
+            const double gm = std::exp(mu * t), g1 = gm * std::exp(t);
+            q.push_back(2.0 * sh * sh);
+            c0.push_back(0.5 * (gm + 1.0 / gm));
+            c1.push_back(0.5 * (g1 + 1.0 / g1));
+        }
+    }
+    // nodes needed for arguments down to x_lo: until x_lo q_j > 745 (the weight underflows) -- the sums stop earlier
+    void reserve_for(double x_lo)
+    {
+        const double t_end = 2.0 * std::asinh(std::sqrt(0.5 * 760.0 / x_lo));
+        extend((size_t)(t_end / h) + 2);
+    }
+    double scaled(double x) const                        // e^x K_nu(x)
+    {
+        double s0 = 0.5, s1 = 0.5;
+        for (size_t j = 0; j < q.size(); ++j) {
+            const double a = x * q[j];
+            if (a > 745.0) break;
+            const double w = std::exp(-a);
+            s0 = std::fma(w, c0[j], s0);
+            s1 = std::fma(w, c1[j], s1);
+            if (w * c1[j] < 1e-19 * s1) break;
+        }
+        double k0 = h * s0, k1 = h * s1;
+        const double two_over_x = 2.0 / x;
+        for (int i = 1; i <= n_up; ++i) {
+            const double up = std::fma((mu + (double)i) * two_over_x, k1, k0);
+            k0 = k1;
+            k1 = up;
+        }
+        return k0;
+    }
+};
+
 // *full (may be nullptr): 1 when [smin, smax] lies inside the tabulated range (nothing was cut at either end)
 inline void matern_tab_build(double nu, double smin, double smax, double scale, double *rows /* nseg x ROW */, int *base_idx,
                              int *nseg, int max_seg, int *full = nullptr)
@@ -308,13 +189,30 @@ inline void matern_tab_build(double nu, double smin, double smax, double scale, 
     tk[1][1] = 1.0;
     for (int k = 2; k < N; ++k)
         for (int j = 0; j < N; ++j) tk[k][j] = (j > 0 ? 2.0 * tk[k - 1][j - 1] : 0.0) - tk[k - 2][j];
-    for (int seg = 0; seg < *nseg; ++seg) {
+    // shared quadrature nodes: arguments up to 6, up to 56, up to 746 (the table ends below 512)
+    const double s_lo = std::ldexp(1.0, e_lo), s_hi = std::ldexp(1.0, e_hi + 1);
+    const double cls_hi[3] = {6.0, 56.0, 746.0};
+    BesselQuadNodes nodes[3];
+    for (int c = 0; c < 3; ++c) {
+        const double lo = (c == 0) ? 0.0 : cls_hi[c - 1];           // the class takes arguments in (lo, cls_hi[c]]
+        if (s_hi <= lo || s_lo > cls_hi[c]) continue;               // no table argument falls into it
+        nodes[c].init(nu, cls_hi[c]);
+        nodes[c].reserve_for(lo > s_lo ? lo : s_lo);
+    }
+    auto kscaled = [&](double x) {
+        const int c = x <= cls_hi[0] ? 0 : (x <= cls_hi[1] ? 1 : 2);
+        return nodes[c].q.empty() ? bessel_k_scaled(nu, x) : nodes[c].scaled(x);
+    };
+    // rows are independent: a few host threads keep the fit well below the kernel's time
+    const int nseg_ = *nseg;
+    auto fit_rows = [&](int seg_b, int seg_e) {
+    for (int seg = seg_b; seg < seg_e; ++seg) {
         const int e = e_lo + seg / SPO, m = seg % SPO;
         const double c = std::ldexp(1.0 + (m + 0.5) / SPO, e), hw = std::ldexp(1.0, e - 1 - MaternTab::LSPO);
         double f[N];
         for (int j = 0; j < N; ++j) {
             const double s = c + hw * cs[1][j];
-            f[j] = std::exp(nu * std::log(s) + s) * bessel_k_nu(nu, s);
+            f[j] = std::exp(nu * std::log(s)) * kscaled(s);
         }
         long double ch[N];
         for (int k = 0; k < N; ++k) {
@@ -330,12 +228,21 @@ inline void matern_tab_build(double nu, double smin, double smax, double scale, 
         }
         for (int j = N; j < MaternTab::ROW; ++j) row[j] = 0.0;
     }
-}
-
-// sigma^2 2^{1-nu}/Gamma(nu) s^nu K_nu(s), s = dist/range  (src/Matern.cpp:73,80; no sqrt(2 nu) scaling there)
-__device__ inline double matern_general(double s, double normcon, double nu)
-{
-    return normcon * exp(nu * log(s)) * bessel_k_nu(nu, s);
+    };
+    unsigned hw = std::thread::hardware_concurrency();
+    int nt = (int)(hw ? (hw > 4 ? 4 : hw) : 2);             // ~0.5 ms of work in all: more threads cost more than they save
+    if (nseg_ < 16 * nt) nt = 1;
+    if (nt <= 1) {
+        fit_rows(0, nseg_);
+    } else {
+        std::vector<std::thread> th;
+        const int chunk = (nseg_ + nt - 1) / nt;
+        for (int t = 0; t < nt; ++t) {
+            const int b0 = t * chunk, e0 = (b0 + chunk < nseg_) ? b0 + chunk : nseg_;
+            if (b0 < e0) th.emplace_back(fit_rows, b0, e0);
+        }
+        for (auto &x : th) x.join();
+    }
 }
 
 }  // namespace gpv

@@ -44,7 +44,6 @@ struct SetArgs {
     //   esqe:   sig0 = s1+s2, sA = s1, cA = 1/r1, sB = s2, cB = 1/r2^2
     double sig0, sA, cA, sB, cB;
     double nug_scalar;       // constant nugget (R/createU.R:74) when nuggets == nullptr
-    BesselTab bt;            // COV_MATERN_GEN: order-dependent constants of K_nu (gpv_bessel.hpp), filled on the host
     const double *mt;        // COV_MATERN_GEN: [mt_nseg][MaternTab::ROW] table of normcon s^nu K_nu(s) e^s (device), or nullptr
     int mt_base, mt_nseg;    //   segment of s = (bits(s) >> 49) - mt_base (gpv_bessel.hpp, matern_tab_segment)
     int mt_full;             //   1: the table covers every pair distance of the plan (no range test per pair needed)

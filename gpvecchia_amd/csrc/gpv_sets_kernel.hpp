@@ -488,8 +488,8 @@ __device__ __forceinline__ double rcp_safe(double x)
     return (r == r) ? r : r0;
 }
 
-// general-nu Matern through the per-launch table (gpv_bessel.hpp, MaternTab); outside its range the series path
-__device__ __forceinline__ double matern_general_seg(const double *mt, int mt_base, int mt_nseg, const BesselTab &bt,
+// general-nu Matern through the per-launch table (gpv_bessel.hpp, MaternTab); outside its range the quadrature of gpv_bessel.hpp
+__device__ __forceinline__ double matern_general_seg(const double *mt, int mt_base, int mt_nseg,
                                                      double s, double normcon, double nu)
 {
     const int seg = matern_tab_segment(s, mt_base);
@@ -498,34 +498,59 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
         const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
         return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg(s);               // (normcon is in the table)
     }
-    return matern_general_tab(bt, s, normcon, nu);
+    return matern_general(s, normcon, nu);
 }
 
-// the same when the table spans the distance range the host derived from the plan (SetArgs::mt_full).  That range comes
-// from the point-to-neighbour distances; the kernel also evaluates neighbour-to-neighbour pairs, which stay inside it for
-// true nearest-predecessor arrays but need not for arrays a caller supplies.  A wave whose 64 segments all sit in the LDS
-// window (the common case) is inside the table by construction and takes no range test; on the global-memory path
-// every lane tests its own segment and a pair outside the table is evaluated by the series (`live` = the pair's value is
-// used: a zero distance is replaced by sigma^2 by the caller and only needs a readable row).
+// General nu inside the unrolled covariance rounds: the table ONLY.  A pair the table does not cover (the table spans the
+// range the host derived from the plan's point-to-neighbour distances; neighbour-to-neighbour pairs stay inside it for true
+// nearest-predecessor arrays but need not for arrays a caller supplies; or there is no table at all: GPV_NO_MATERN_TABLE,
+// a range beyond 80 octaves) is FLAGGED (`redo`) and gets its exact value after the rounds, from one copy of the quadrature
+// in a loop of its own (cov_rounds_fast): inlined at the 60 places of the rounds, that fallback cost the hot path hundreds
+// of spilled registers.  A wave whose 64 segments all sit in the LDS window (the common case) is inside the table by
+// construction and takes no range test.  `live` = the pair's value is used (a zero distance is replaced by sigma^2).
 template <int MTW>
-__device__ __forceinline__ double matern_table_only(const SetArgs &A, const double *mt_lds, double s, bool live, const ExpScaled &E)
+__device__ __forceinline__ double matern_table_only(const SetArgs &A, const double *mt_lds, double s, bool live, const ExpScaled &E,
+                                                    unsigned long long &need, const int bit)
 {
     const int seg0 = matern_tab_segment(s, A.mt_base);
     if constexpr (MTW > 0) {
         const int rel = seg0 - A.mt_win;
-        const bool in = (unsigned)rel < (unsigned)MTW;
+        const bool in = (unsigned)rel < (unsigned)MTW && A.mt_nseg > 0;
         if (__builtin_amdgcn_ballot_w64(!in) == 0) {                // wave uniform: every lane's segment sits in the LDS window
             const double2 *row = reinterpret_cast<const double2 *>(mt_lds + rel * kMtRowLds);
             const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
             return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
         }
     }
-    const bool inside = (unsigned)seg0 < (unsigned)A.mt_nseg;
-    if (live && !inside) return matern_general_tab(A.bt, s, A.sA, A.sB);   // rare, divergent: a pair the table does not cover
+    need |= (unsigned long long)(live && !((unsigned)seg0 < (unsigned)A.mt_nseg)) << bit;   // (only this path pays for the flag)
+    if (A.mt_nseg <= 0) return 0.0;                                 // no table (kernel argument: uniform)
     const int seg = seg0 < 0 ? 0 : (seg0 >= A.mt_nseg ? A.mt_nseg - 1 : seg0);
     const double2 *row = reinterpret_cast<const double2 *>(A.mt + (size_t)seg * MaternTab::ROW);
     const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
     return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);
+}
+
+// General nu, the pairs the table did not cover (bit s - 1 of `need`: the pair of row rq and its partner of round s), exactly:
+// normcon s^nu K_nu(s) by the quadrature of gpv_bessel.hpp (src/Matern.cpp:72-84), written over the value the lane staged
+// in the packed triangle.  A real call (never inlined): rare, divergent, and large.
+// xy0 / tr0: LDS byte addresses of the set's staged coordinates and triangle; xs_row / xs_dim: the coordinates' strides.
+static __device__ __attribute__((noinline)) void matern_gen_fixup(unsigned long long need, int rq, int P_, int H_, int dim, unsigned xy0,
+                                                                  int xs_row, int xs_dim, unsigned tr0, double x0, double x1, double x2,
+                                                                  double r2init, double cmul, double normcon, double nu)
+{
+    for (int s = 1; s <= H_; ++s) {
+        if (!((need >> (s - 1)) & 1ull)) continue;
+        const int j = (rq + s < P_) ? rq + s : rq + s - P_;
+        const lds_cdouble *xj = lds_ptr(xy0 + (unsigned)(j * xs_row) * 8u);
+        double df = x0 - xj[0];
+        double r2 = __builtin_fma(df, df, r2init);
+        if (dim > 1) { df = x1 - xj[xs_dim]; r2 = __builtin_fma(df, df, r2); }
+        if (dim > 2) { df = x2 - xj[2 * xs_dim]; r2 = __builtin_fma(df, df, r2); }
+        const double sd = sqrt(__builtin_fmax(r2, 2.2250738585072014e-308));
+        const double sarg = __builtin_fmin(sd * cmul, 1.0e4);
+        const int hi = rq > j ? rq : j, lo = rq > j ? j : rq;
+        *lds_wptr(tr0 + (unsigned)((hi * (hi + 1)) / 2 + lo) * 8u) = matern_general(sarg, normcon, nu);
+    }
 }
 
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
@@ -546,7 +571,7 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
         const double t = dist * cA;                 // sqrt(5) * dist / range
         v = sA * exp_neg(t) * __builtin_fma(t, __builtin_fma(t, 1.0 / 3.0, 1.0), 1.0);   // src/Matern.cpp:68
     } else if constexpr (COV == COV_MATERN_GEN) {
-        v = (r2 == 0.0) ? sig0 : matern_general_seg(A.mt, A.mt_base, A.mt_nseg, A.bt, dist * cA, sA, sB);   // src/Matern.cpp:72-84
+        v = (r2 == 0.0) ? sig0 : matern_general_seg(A.mt, A.mt_base, A.mt_nseg, dist * cA, sA, sB);   // src/Matern.cpp:72-84
     } else {
         v = __builtin_fma(sA, exp_neg(dist * cA), sB * exp_neg(r2 * cB));                // src/Esqe.cpp:33-35
     }
@@ -558,25 +583,19 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
 // SCALED: the coordinates were multiplied by cA (= sqrt(2 nu)/range) when they were gathered, sqrt(r2) is t itself;
 // R2MIN: r2 was accumulated from the smallest normal number (coincident points give exactly that), no clamp needed
-template <int COV, bool TAB = false, int MTW = 0, bool SCALED = false, bool R2MIN = false>
+template <int COV, int MTW = 0, bool SCALED = false, bool R2MIN = false>
 __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, double cA, double sB, double cB,
-                                             const SetArgs &A, const ExpScaled &E, const double *mt_lds = nullptr)
+                                             const SetArgs &A, const ExpScaled &E, const double *mt_lds,
+                                             unsigned long long &need, const int bit, const bool pair_used = true)
 {
     constexpr double kTiny = 2.2250738585072014e-308;
-    if constexpr (COV == COV_MATERN_GEN && TAB) {
+    if constexpr (COV == COV_MATERN_GEN) {
         const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
         const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
         // (s clamped for the same reason as t below; s^nu K_nu(s) is 0 in FP64 from s ~ 800 for every nu <= 60)
-        const double v = matern_table_only<MTW>(A, mt_lds, __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4), live, E);
+        const double v = matern_table_only<MTW>(A, mt_lds, __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4), live && pair_used, E, need, bit);
         return live ? v : sig0;                                      // src/Matern.cpp:76
     }
-    if constexpr (COV == COV_MATERN_GEN && (SCALED || R2MIN)) {      // series path on prepared operands
-        const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
-        const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
-        const double v = matern_general_seg(A.mt, A.mt_base, A.mt_nseg, A.bt, __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4), sA, sB);
-        return live ? v : sig0;
-    }
-    if constexpr (COV == COV_MATERN_GEN) return cov_from_r2<COV>(r2, sig0, sA, cA, sB, cB, A);
     if constexpr (!R2MIN) r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
     const double dist = sqrt_pos(r2);
     // t is clamped HERE, before its polynomial use as well: v_min_f64 returns 1000 for a NaN, and the only NaN that can reach
@@ -608,7 +627,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     constexpr int MTW = mt_window_rows<P, D, COV>();
     __shared__ __attribute__((aligned(16))) double mt_lds[MTW > 0 ? MTW * kMtRowLds : 2];
     if constexpr (MTW > 0) {
-        if (A.mt_full) {                                 // rows [mt_win, mt_win + MTW) of this launch's table (clamped at its end)
+        if (A.mt_nseg > 0) {                             // rows [mt_win, mt_win + MTW) of this launch's table (clamped at its end)
             constexpr int RC = MaternTab::ROW / 2;           // 16-byte pieces per row
             for (int t = threadIdx.x; t < MTW * RC; t += W * 64) {
                 const int r = t / RC, c = t - r * RC;
@@ -839,9 +858,11 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         // round and the body is one basic block (loads of the next pair overlap the arithmetic of this one).
         // Addresses: with rt = r(r+1)/2 the pair (r, r+s) lives at rt + r(s+1) + s(s+1)/2 if r+s < P, else (it wraps
         // to j = r+s-P < r) at rt + j; the constant s(s+1)/2 rides in the instruction's offset field.
-        auto cov_rounds_fast = [&](auto masked_tag, auto tab_tag) {
+        auto cov_rounds_fast = [&](auto masked_tag) {
             constexpr bool MASKED = decltype(masked_tag)::value;
-            constexpr bool TAB = decltype(tab_tag)::value;           // general nu: table-only evaluation (no per-pair range test)
+            unsigned long long need[RPL];                            // general nu: pairs (round s = bit s - 1) to be redone exactly
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) need[q] = 0ull;
             constexpr int DS = Lds::DS, DD = (D == 0) ? 1 : D;
             // absolute 32-bit LDS byte addresses, the slices' bases folded into the per-lane terms: per pair one select for the
             // partner's coordinates, one add and one select for the triangle slot, the round's constants in the DS offset field
@@ -896,7 +917,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         const double df = xq[q][t] - xc[q][t];
                         r2 = __builtin_fma(df, df, r2);
                     }
-                    v[q] = cov_closed<COV, TAB, MTW, PRESCALE, R2MIN>(r2, sig0, sA, cA, sB, cB, A, expS, mt_lds);
+                    bool used = true;
                     if constexpr (MASKED) {                          // padded rows/cols -> identity
                         const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
                         bool jvalid = false;
@@ -905,8 +926,10 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                             const int jl = j - q2 * LPS;
                             if (jl >= 0 && jl < LPS) jvalid = (vmask[q2] >> (sub * LPS + jl)) & 1ull;
                         }
-                        v[q] = (vq[q] && jvalid) ? v[q] : 0.0;
+                        used = vq[q] && jvalid;
                     }
+                    v[q] = cov_closed<COV, MTW, PRESCALE, R2MIN>(r2, sig0, sA, cA, sB, cB, A, expS, mt_lds, need[q], s - 1, used);
+                    if constexpr (MASKED) v[q] = used ? v[q] : 0.0;
                 }
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
@@ -914,20 +937,24 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     trA[q] += rq8[q] + 8 * s;                        // to round s + 1
                 }
             }
+            if constexpr (COV == COV_MATERN_GEN) {
+                // the flagged pairs again, exactly (matern_gen_fixup: a real function call, so that the quadrature, its loop and
+                // its library functions exist once per code object and not inside this loop); the lane overwrites what it staged
+                bool any = false;
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) any = any || (need[q] != 0ull);
+                if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q)
+                        matern_gen_fixup(need[q], rq[q], P, H, D, xy0, Lds::XS_ROW, Lds::XS_DIM, tr0, xq[q][0], D > 1 ? xq[q][D > 1 ? 1 : 0] : 0.0,
+                                         D > 2 ? xq[q][D > 2 ? 2 : 0] : 0.0, R2MIN ? 2.2250738585072014e-308 : 0.0, PRESCALE ? 1.0 : cA,
+                                         sA, sB);
+                }
+            }
         };
         if constexpr (D != 0 && COV != COV_DENSE) {
-            if constexpr (COV == COV_MATERN_GEN) {
-                if (A.mt_full) {                                 // kernel argument: uniform
-                    if (all_valid) cov_rounds_fast(std::false_type{}, std::true_type{});
-                    else cov_rounds_fast(std::true_type{}, std::true_type{});
-                } else {
-                    if (all_valid) cov_rounds_fast(std::false_type{}, std::false_type{});
-                    else cov_rounds_fast(std::true_type{}, std::false_type{});
-                }
-            } else {
-                if (all_valid) cov_rounds_fast(std::false_type{}, std::false_type{});   // wave-uniform: the common case has no padding
-                else cov_rounds_fast(std::true_type{}, std::false_type{});
-            }
+            if (all_valid) cov_rounds_fast(std::false_type{});   // wave-uniform: the common case has no padding
+            else cov_rounds_fast(std::true_type{});
         } else {
             if (all_valid) cov_rounds(std::false_type{});
             else cov_rounds(std::true_type{});
