@@ -31,7 +31,7 @@ EXPORTS = [
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
     "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms", "gpv_plan_set_kernel_timing",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
-    "gpv_plan_build_posterior", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
+    "gpv_plan_build_posterior", "gpv_plan_build_posterior_fill", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
     "gpv_plan_cache_clear", "gpv_plan_cache_stats", "gpv_plan_vl_begin", "gpv_plan_vl_step", "gpv_plan_vl_get",
     "gpv_plan_set_user_order", "gpv_plan_vl_begin_user", "gpv_plan_vl_restart", "gpv_plan_vl_get_user", "gpv_plan_vl_loglik",
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
@@ -94,6 +94,7 @@ def lib():
     L.gpv_numerator_from_sums.argtypes = [dp, dp, dp]
     L.gpv_plan_build_posterior.argtypes = [vp, ip, ip]
     L.gpv_plan_posterior_levels.argtypes = [vp, ip]
+    L.gpv_plan_build_posterior_fill.argtypes = [vp, ip, ip, C.c_double, dp]
     L.gpv_plan_get_posterior_mean.argtypes = [vp, dp]
     L.gpv_loglik_from_sums.argtypes = [dp, i64, dp]
     L.gpv_mplan_create.argtypes = [C.POINTER(vp), ip, C.c_int, i64, C.c_int, C.c_int, dp, ip, ip]

@@ -55,6 +55,23 @@ class Plan:
         L.check(L.lib().gpv_plan_posterior_levels(self._h, C.byref(nl)), "gpv_plan_posterior_levels")
         return int(nl.value)
 
+    def build_posterior_fill(self, max_fill=4.0):
+        """Structure of the U2V pass on the FILLED pattern (cond.yz='y': the factor fills in, R/vecchia_prediction.R:72-83).
+        Returns the fill ratio, or None when the library refuses (fill beyond max_fill x the latent block, or a column of the
+        factor beyond 64 rows): the caller then factorises on the host like the reference's CHOLMOD."""
+        if getattr(self, "_fill_refused", False):
+            return None
+        ratio = C.c_double(0.0)
+        st = L.lib().gpv_plan_build_posterior_fill(self._h, L.iptr(self._nn), L.iptr(self._cd), float(max_fill), C.byref(ratio))
+        if st == 5:                                       # GPV_ERR_UNSUPPORTED_M: bounded out
+            self._fill_refused = True
+            self.fill_ratio = float(ratio.value)
+            return None
+        L.check(st, "gpv_plan_build_posterior_fill")
+        self.has_posterior = True
+        self.fill_ratio = float(ratio.value)
+        return self.fill_ratio
+
     def posterior_levels(self):
         """Number of levels of the posterior pass's schedule (after build_posterior)."""
         nl = C.c_int()
@@ -758,5 +775,14 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         plan.set_user_data(z, va["ord_z"])
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_DENOM)
         return loglik_from_sums(plan.sums(), n)
+    if plain and va["cond_yz"] == "y" and isinstance(covmodel, str) and not np.any(nug == 0) and \
+            va["U_prep"]["revNNarray"].shape[1] <= 64 and not va.get("ic0", False):
+        # latent conditioning throughout: W = U_y U_y^T fills in.  The device pass runs on the filled pattern when the fill is
+        # bounded (symbolic factorisation on the host, once per plan); otherwise the host factorisation below, like CHOLMOD
+        plan = _plan_for(va, device)
+        if plan.has_posterior or plan.build_posterior_fill() is not None:
+            plan.set_user_data(z, va["ord_z"])
+            plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_DENOM)
+            return loglik_from_sums(plan.sums(), n)
     U_obj = createU(va, covparms, nug, covmodel, device=device)
     return vecchia_likelihood_U(z, U_obj)

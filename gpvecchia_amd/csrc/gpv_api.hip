@@ -263,6 +263,7 @@ struct gpv_plan {
     double2 *d_C = nullptr;
     int32_t *d_cboff = nullptr, *d_cdel = nullptr;   // block offsets in d_C (Morton order of the locations), and cboff - colptr
     int64_t post_nnz = 0;
+    int post_ld = 0;                                 // bound of the entries per column of the posterior structure (>= P; more with fill)
     uint8_t *d_cslot = nullptr;
     double *d_avec = nullptr, *d_tvec = nullptr, *d_rdiag = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
@@ -782,7 +783,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         pa.C = pl->d_C; pa.cboff = pl->d_cboff; pa.z = pl->d_zuser;
         pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
         pa.nug_cell = pl->d_nug_post;
-        pa.tvec = pl->d_tvec; pa.rdiag = pl->d_rdiag; pa.ld = pl->P;
+        pa.tvec = pl->d_tvec; pa.rdiag = pl->d_rdiag; pa.ld = pl->post_ld;
         const bool want_mean = (flags & GPV_WANT_MEAN) != 0;
         // cond.yz = 'zy' (R/vecchia_prediction.R:68-70,118-126): V.ord is the reversed latent block B of U itself, no
         // factorisation.  After createU's removal of the dummy latent variables (R/createU.R:166-171) no latent row has an
@@ -864,10 +865,25 @@ int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int
     return plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
 }
 
+static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCond, bool with_fill, double max_fill,
+                                double *fill_ratio);
+
 int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
+{
+    return build_posterior_impl(pl, revNN, revCond, false, 0.0, nullptr);
+}
+
+int gpv_plan_build_posterior_fill(gpv_plan *pl, const int *revNN, const int *revCond, double max_fill, double *fill_ratio)
+{
+    return build_posterior_impl(pl, revNN, revCond, true, max_fill, fill_ratio);
+}
+
+static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCond, bool with_fill, double max_fill,
+                                double *fill_ratio)
 {
     // symbolic structure of the latent block B of U (R/U_sparsity.R:36-56 restricted to latent rows) as column
     // lists, row lists and a level schedule; parameter independent, built once.
+    if (fill_ratio) *fill_ratio = 1.0;
     if (!pl || !revNN || !revCond) return GPV_ERR_BAD_ARG;
     if (pl->row_begin != 0 || pl->row_end != pl->Nlocs) return GPV_ERR_BAD_ARG;   // not shardable
     if (pl->p > 64) return GPV_ERR_UNSUPPORTED_M;      // the level kernels own one lane per row of a column (<= 64)
@@ -897,7 +913,6 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
                 if (tmp[t] > (int32_t)k) return GPV_ERR_BAD_ARG;                  // neighbours precede the point
                 crow.push_back(tmp[t]);
                 cslot.push_back((uint8_t)t);
-                rowcnt[(size_t)tmp[t] + 1]++;
             }
         }
         colptr[(size_t)k + 1] = (int32_t)crow.size();
@@ -912,7 +927,74 @@ int gpv_plan_build_posterior(gpv_plan *pl, const int *revNN, const int *revCond)
             }
         }
     }
+    int maxcnt = p;
+    if (with_fill) {
+        // cond.yz = 'y' (R/vecchia_prediction.R:72-83): W = B B^T + D^-1 couples every two rows of a column, and the UL factor
+        // R (= what t(chol(rev(W))) holds, reversed) fills in beyond the pattern of B.  Symbolic factorisation, last column
+        // first: struct(R_.k) = {rows i <= k of W_.k} u U over the columns c whose parent is k of (struct(R_.c) minus c), parent(c) =
+        // the largest row below c in struct(R_.c) (the elimination tree of the reversed matrix).  On the FILLED pattern, with
+        // zeros where B has no entry, the fixed-pattern factorisation of the level kernels drops nothing: it is exact.
+        // Bounded: refused when the filled pattern exceeds max_fill times nnz(B) or a column outgrows the 64 lanes of a
+        // wavefront (the caller then factorises on the host, like the reference's CHOLMOD).
+        const size_t nnzB = crow.size();
+        std::vector<int32_t> rp((size_t)n + 1, 0);                       // row lists of B: columns c >= k that contain row k
+        for (size_t e = 0; e < nnzB; ++e) rp[(size_t)crow[e] + 1]++;
+        for (int64_t i = 0; i < n; ++i) rp[(size_t)i + 1] += rp[(size_t)i];
+        std::vector<int32_t> rl(nnzB), fillpos(rp.begin(), rp.end() - 1);
+        for (int64_t k = 0; k < n; ++k)
+            for (int32_t e = colptr[(size_t)k]; e < colptr[(size_t)k + 1]; ++e) rl[(size_t)fillpos[(size_t)crow[(size_t)e]]++] = (int32_t)k;
+        std::vector<std::vector<int32_t>> st((size_t)n);                 // struct(R_.k), ascending, k last
+        std::vector<std::vector<int32_t>> child((size_t)n);
+        std::vector<int32_t> mark((size_t)n, -1), buf;
+        size_t total = 0;
+        const size_t budget = (size_t)(max_fill > 0.0 ? max_fill * (double)nnzB : 4.0 * (double)nnzB) + (size_t)n;
+        for (int64_t k = n - 1; k >= 0; --k) {
+            buf.clear();
+            auto add = [&](int32_t i) {
+                if (i <= (int32_t)k && mark[(size_t)i] != (int32_t)k) { mark[(size_t)i] = (int32_t)k; buf.push_back(i); }
+            };
+            for (int32_t q = rp[(size_t)k]; q < rp[(size_t)k + 1]; ++q) {   // W_.k: rows of every column of B that holds row k
+                const int32_t c = rl[(size_t)q];
+                for (int32_t e = colptr[(size_t)c]; e < colptr[(size_t)c + 1]; ++e) add(crow[(size_t)e]);
+            }
+            for (int32_t c : child[(size_t)k])
+                for (int32_t i : st[(size_t)c]) if (i != c) add(i);
+            std::sort(buf.begin(), buf.end());
+            if (buf.empty() || buf.back() != (int32_t)k) return GPV_ERR_BAD_ARG;
+            total += buf.size();
+            if (buf.size() > 64 || total > budget) {
+                // (the ratio over the columns processed so far: the fill grows towards the early columns, so this is a lower bound)
+                const size_t seen = nnzB - (size_t)colptr[(size_t)k];
+                if (fill_ratio) *fill_ratio = (double)total / (double)(seen ? seen : 1);
+                return GPV_ERR_UNSUPPORTED_M;
+            }
+            if (buf.size() >= 2) child[(size_t)buf[buf.size() - 2]].push_back((int32_t)k);   // parent = largest row below k
+            st[(size_t)k] = buf;
+        }
+        if (fill_ratio) *fill_ratio = (double)total / (double)(nnzB ? nnzB : 1);
+        // the filled columns replace B's: an entry B has carries its Lentries slot, a fill entry 0xFF (the compaction writes 0)
+        std::vector<int32_t> colptr2((size_t)n + 1, 0), crow2;
+        std::vector<uint8_t> cslot2;
+        crow2.reserve(total);
+        cslot2.reserve(total);
+        for (int64_t k = 0; k < n; ++k) {
+            int32_t e = colptr[(size_t)k];
+            const int32_t e1 = colptr[(size_t)k + 1];
+            for (int32_t i : st[(size_t)k]) {
+                while (e < e1 && crow[(size_t)e] < i) ++e;
+                crow2.push_back(i);
+                cslot2.push_back((e < e1 && crow[(size_t)e] == i) ? cslot[(size_t)e] : (uint8_t)0xFF);
+            }
+            colptr2[(size_t)k + 1] = (int32_t)crow2.size();
+            if ((int)st[(size_t)k].size() > maxcnt) maxcnt = (int)st[(size_t)k].size();
+        }
+        colptr.swap(colptr2);
+        crow.swap(crow2);
+        cslot.swap(cslot2);
+    }
+    pl->post_ld = maxcnt > pl->P ? maxcnt : pl->P;
     const size_t nnz = crow.size();
+    for (size_t e = 0; e < nnz; ++e) rowcnt[(size_t)crow[e] + 1]++;
     std::vector<int32_t> rowptr((size_t)n + 1, 0);
     for (int64_t i = 0; i < n; ++i) rowptr[(size_t)i + 1] = rowptr[(size_t)i] + rowcnt[(size_t)i + 1];
     std::vector<int32_t> fill(rowptr.begin(), rowptr.end() - 1), rcol(nnz), qof(nnz);

@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(256) gpv_posterior_compact_kernel(const double
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < nnz; g += stride) {
         const int c = ccol[g];
-        const double b = L[(int64_t)c * ld + cslot[g]];
+        const unsigned sl = cslot[g];
+        const double b = (sl == 0xFFu) ? 0.0 : L[(int64_t)c * ld + sl];          // 0xFF: a fill entry of cond.yz = 'y' (B has none there)
         C[g + cdel[c] + 1] = make_double2(b, both ? b : 0.0);
     }
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += stride)

@@ -183,6 +183,14 @@ int gpv_plan_eval(gpv_plan *plan, const char *covType, const double *covparms, i
  * Requires a plan that owns all rows.  For SGV the factor has no fill, so the fixed-pattern factorisation is
  * exact; for other conditioning patterns it is the zero-fill incomplete factor (the reference's ic0=TRUE). */
 int gpv_plan_build_posterior(gpv_plan *plan, const int *revNNarray, const int *revCondOnLatent);
+/* The same for patterns that are not cliques -- cond.yz='y' (latent conditioning throughout, R/vecchia_specify.R:186-187), whose
+ * factor fills in (R/vecchia_prediction.R:72-83; the reference calls CHOLMOD): the structure is built on the FILLED pattern
+ * (symbolic factorisation on the host, once), on which the fixed-pattern factorisation is exact.  Bounded: returns
+ * GPV_ERR_UNSUPPORTED_M -- the caller then factorises on the host -- when the filled pattern exceeds max_fill (<= 0: 4) times
+ * the entries of the latent block or a column of the factor outgrows 64 rows.  *fill_ratio (may be NULL): filled entries /
+ * entries of the latent block (when refused: over the columns processed up to the refusal, a lower bound). */
+int gpv_plan_build_posterior_fill(gpv_plan *plan, const int *revNNarray, const int *revCondOnLatent, double max_fill,
+                                  double *fill_ratio);
 int gpv_plan_posterior_levels(gpv_plan *plan, int *n_levels);
 /* blocking: mu.ord (length Nlocs, ordered layout) after an eval with GPV_WANT_MEAN */
 int gpv_plan_get_posterior_mean(gpv_plan *plan, double *mu_ord);

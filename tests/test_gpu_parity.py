@@ -1282,3 +1282,56 @@ def test_replica_plans_evaluate_different_parameters_concurrently():
     assert L.lib().gpv_mplan_eval(rp._h, b"matern", L.dptr(cp), 3, L.dptr(tau), 1, G.GPV_WANT_LOGLIK_Z, L.dptr(s)) == 2
     mp = G.MultiPlan(pva["locsord"], prep["revNNarray"], prep["revCond"], devices=[0, 0])
     assert L.lib().gpv_mplan_build_posterior(mp._h, L.iptr(rp._nn), L.iptr(rp._cd)) == 2     # shards cannot run the pass
+
+
+def test_cond_y_denominator_on_the_device_with_bounded_fill():
+    """cond.yz='y' (latent conditioning throughout): W = U_y U_y^T is not block-clique and its factor fills in
+    (R/vecchia_prediction.R:72-83, CHOLMOD in the reference).  The device pass runs on the symbolically filled pattern, where
+    the fixed-pattern factorisation is exact, as long as the fill stays bounded (<= 4 x the latent block, <= 64 rows per
+    column); beyond that the library refuses and the host factorises.  Fill is small in one dimension (banded) and for tiny
+    two-dimensional sets; at n = 2000, m = 10 in 2-D the filled pattern is 32 x the block (312 x at n = 2e4: measured on the
+    host) and the host path answers."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    from gpvecchia_amd import api as A
+    # (1) tiny 2-D set, maxmin: fill ratio ~3, every column of the factor within a wavefront
+    rng = np.random.default_rng(3)
+    n, m = 150, 6
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    cp, tau = [1.0, 0.3, 1.5], 0.2
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="y")
+    ll_ref = R.vecchia_likelihood(z, vb, cp, tau)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="y")
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    plan = va[("_plan", 0)]
+    assert plan.has_posterior and 1.5 < plan.fill_ratio <= 4.0, plan.fill_ratio      # the device pass ran, on a filled pattern
+    assert abs(ll - ll_ref) <= 1e-9 * abs(ll_ref)
+    ll_host = A.vecchia_likelihood_U(z, A.createU(va, cp, tau))                       # SuperLU, like the reference's CHOLMOD
+    assert abs(ll - ll_host) <= 1e-10 * abs(ll_host)
+    # (2) one dimension, n = 2e4, m = 10: banded, hardly any fill
+    n, m = 20000, 10
+    locs = np.sort(rng.random((n, 1)), axis=0); z = rng.standard_normal(n)
+    cp, tau = [1.0, 0.002, 0.5], 0.1
+    va = G.vecchia_specify(locs, m, ordering="coord", cond_yz="y")
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    plan = va[("_plan", 0)]
+    assert plan.has_posterior and plan.fill_ratio < 2.0, plan.fill_ratio
+    s = plan.sums()                                                                  # (createU below evaluates the same plan again)
+    U_obj = A.createU(va, cp, tau)
+    ll_host = A.vecchia_likelihood_U(z, U_obj)
+    assert abs(ll - ll_host) <= 1e-9 * abs(ll_host)
+    lat = U_obj["latent"]
+    Uy = U_obj["U"].tocsr()[np.where(lat)[0], :]
+    import scipy.sparse.linalg as spla
+    lu = spla.splu((Uy @ Uy.T).tocsc(), permc_spec="NATURAL", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    np.testing.assert_allclose(s[2], np.sum(np.log(lu.U.diagonal())), rtol=1e-9)     # logdet.denom = -log det W
+    # (3) 2-D at n = 2000: bounded out, the host path answers
+    n, m = 2000, 10
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="y")
+    ll = G.vecchia_likelihood(z, va, [1.0, 0.1, 1.5], 0.1)
+    plan = va[("_plan", 0)]
+    assert not plan.has_posterior and plan._fill_refused and plan.fill_ratio > 1.0     # (a column of the factor beyond 64 rows)
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="y")
+    ll_ref = R.vecchia_likelihood(z, vb, [1.0, 0.1, 1.5], 0.1)
+    assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
