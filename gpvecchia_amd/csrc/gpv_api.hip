@@ -282,6 +282,7 @@ struct gpv_plan {
     hipEvent_t mt_ev[2] = {nullptr, nullptr};
     int mt_slot = 0, mt_pending = -1;
     int32_t *d_order2 = nullptr, *d_levptr2 = nullptr;
+    int4 *d_meanrec = nullptr;                       // mean sweep: one record per column in schedule order
     double *d_toppart = nullptr;                     // [top_K][66] partial sums of the top block's columns
     int top_K = 0;                                   // columns 0 .. top_K-1 are kept out of the schedule (gpv_posterior_ext.h)
     int mean_head_levels = 0;                        // leading levels of the mean sweep run by one workgroup
@@ -361,7 +362,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket,
-                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord};
+                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -784,6 +785,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
         pa.nug_cell = pl->d_nug_post;
         pa.tvec = pl->d_tvec; pa.rdiag = pl->d_rdiag; pa.ld = pl->post_ld;
+        pa.meanrec = pl->d_meanrec;
         const bool want_mean = (flags & GPV_WANT_MEAN) != 0;
         // cond.yz = 'zy' (R/vecchia_prediction.R:68-70,118-126): V.ord is the reversed latent block B of U itself, no
         // factorisation.  After createU's removal of the dummy latent variables (R/createU.R:166-171) no latent row has an
@@ -1174,6 +1176,14 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     GPV_HIP(hipMalloc((void **)&pl->d_C, sizeof(double2) * (nnz + (size_t)n)));
     pl->post_nnz = (int64_t)nnz;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
+    {
+        std::vector<int4> meanrec((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t k = order2[(size_t)i];
+            meanrec[(size_t)i] = make_int4(k, cboff[(size_t)k], colptr[(size_t)k + 1] - colptr[(size_t)k], colptr[(size_t)k]);
+        }
+        if ((rc = up((void **)&pl->d_meanrec, meanrec.data(), meanrec.size() * sizeof(int4))) != GPV_OK) return rc;
+    }
     if ((rc = up((void **)&pl->d_levptr2, pl->levptr2.data(), pl->levptr2.size() * 4)) != GPV_OK) return rc;
     if (pl->d_toppart) { (void)hipFree(pl->d_toppart); pl->d_toppart = nullptr; }
     if (pl->top_K > 0) GPV_HIP(hipMalloc((void **)&pl->d_toppart, sizeof(double) * 66 * (size_t)pl->top_K));

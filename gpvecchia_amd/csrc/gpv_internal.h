@@ -96,6 +96,7 @@ struct PostArgs {
     double *tvec;            // [n] solution of R t = z2
     double *rdiag;           // [n] R_kk (the logarithms are taken by the reduction that sums them)
     int ld;                  // row length of Lentries (bounds the entries per column)
+    const int4 *meanrec;     // [n] mean sweep: {k, cboff[k], entries, colptr[k]} in the order of its schedule, or nullptr
 };
 // C <- (Lentries, a): ccol/cslot give column and Lentries slot of every compact entry
 // cdel[c] = cboff[c] - colptr[c]

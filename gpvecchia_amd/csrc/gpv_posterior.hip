@@ -688,9 +688,38 @@ __global__ void __launch_bounds__(256) gpv_mean_level_kernel(const PostArgs A, c
     rkk = __shfl(rkk, cnt - 1, 64);
     if (lane == 0) u[k] = (A.tvec[k] - part) / rkk;
 }
+// The same with one record per column of the schedule, {k, block offset, entries, first entry}, instead of the chain
+// order2 -> colptr / cboff -> entries: three dependent trips to memory per column instead of four (the sweep is nothing but
+// such chains: 77 levels of 6.6 us each at n = 5e5 before), and LPC = 32 lanes per column where no column has more than 32
+// entries (two columns per wavefront).
+template <int LPC>
+__global__ void __launch_bounds__(256) gpv_mean_level_rec_kernel(const PostArgs A, const int4 *meanrec, double *u, int first, int count)
+{
+    const int lane = threadIdx.x & 63, l = lane % LPC;
+    const int w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LPC) + lane / LPC;
+    const bool live = w < count;
+    const int4 rec = nt_load(&meanrec[first + (live ? w : 0)]);
+    const int k = rec.x, cnt = rec.z;
+    double part = 0.0, rkk = 1.0;
+    const double tk = A.tvec[k];
+    if (l < cnt) {
+        const int i = __builtin_nontemporal_load(&A.crow[rec.w + l]);
+        const double r = A.C[(int64_t)rec.y + 1 + l].y;
+        if (l == cnt - 1) rkk = r; else part = r * u[i];
+    }
+#pragma unroll
+    for (int off = LPC / 2; off > 0; off >>= 1) part += __shfl_down(part, off, LPC);
+    rkk = __shfl(rkk, cnt - 1, LPC);
+    if (live && l == 0) u[k] = (tk - part) / rkk;
+}
 hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u, int first, int count, hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
+    if (a.meanrec != nullptr) {
+        if (a.ld <= 32) hipLaunchKernelGGL((gpv_mean_level_rec_kernel<32>), dim3((count + 7) / 8), dim3(256), 0, s, a, a.meanrec, u, first, count);
+        else hipLaunchKernelGGL((gpv_mean_level_rec_kernel<64>), dim3((count + 3) / 4), dim3(256), 0, s, a, a.meanrec, u, first, count);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gpv_mean_level_kernel, dim3((count + 3) / 4), dim3(256), 0, s, a, order2, u, first, count);
     return hipGetLastError();
 }
