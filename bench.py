@@ -252,8 +252,18 @@ def dropin_config(n, locs, revNN, revCond, covparms, tau):
         t.append(time.perf_counter() - t0)
         L.check(status.value, "gpv_U_NZentries")
     dk_ok = bool(np.all(Lent[np.arange(0, n, 9973), (nn[::9973] != 0).sum(axis=1) - 1] > 0))
+    tf = []
+    for it in range(3):                               # outputs allocated anew per call, as R's .C() does: first-touch page faults
+        Lf, Zf = np.empty((n, p), order="F"), np.empty(2 * n)
+        t0 = time.perf_counter()
+        L.lib().gpv_U_NZentries(ci(1), ci(n), ci(n), ci(lf.shape[1]), ci(p), L.dptr(lf), L.iptr(nn), L.iptr(cd), L.dptr(nug),
+                                L.dptr(nug), C.byref(ct), L.dptr(cp), ci(cp.size), L.dptr(Lf), L.dptr(Zf), C.byref(nfail),
+                                C.byref(status))
+        tf.append(time.perf_counter() - t0)
+        del Lf, Zf
     L.lib().gpv_plan_cache_clear()
-    return {"first_call_ms": 1e3 * t[0], "ms_per_call": 1e3 * float(np.median(t[1:])), "n_failed": int(nfail.value),
+    return {"first_call_ms": 1e3 * t[0], "ms_per_call": 1e3 * float(np.median(t[1:])),
+            "ms_per_call_fresh_outputs": 1e3 * float(np.median(tf)), "n_failed": int(nfail.value),
             "diag_positive_on_sample": dk_ok, "bytes_to_host": int(8 * n * p + 16 * n),
             "what": "mode U+D2H: the C symbol gpv_U_NZentries at C3 with host buffers in and out (caller-allocated outputs), plan "
                     "cached from the first call; includes content hash, nuggets H2D, kernel, transpose and the D2H copy"}

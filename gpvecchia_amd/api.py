@@ -254,6 +254,22 @@ class ReplicaPlans:
         return np.array([loglik_from_sums(r, self.Nlocs) for r in s])
 
 
+_R_LAYOUT_CACHE = []          # [(revNNarray, revCond, nn_r, cd_r)]: the R-layout copies of the last two index-array pairs
+
+
+def _r_layout_cached(revNNarray, revCond):
+    """Column-major int32 copies (R's representation) of the two index arrays, kept for the arrays last seen: createU hands
+    the SAME objects to U_NZentries at every optimiser step, and converting 2 x 31e6 entries costs ~60 ms, six times the
+    library call.  Keyed by object identity: arrays are treated as immutable once handed over (the reference's R semantics)."""
+    for a, b, nn_r, cd_r in _R_LAYOUT_CACHE:
+        if a is revNNarray and b is revCond:
+            return nn_r, cd_r
+    nn_r, cd_r = L.as_r_int_matrix(revNNarray), _cond_to_r(revCond)
+    _R_LAYOUT_CACHE.insert(0, (revNNarray, revCond, nn_r, cd_r))
+    del _R_LAYOUT_CACHE[2:]
+    return nn_r, cd_r
+
+
 def _cond_to_r(revCond):
     """logical matrix -> R's int representation: NaN (float input) or -1 (int8 input) -> NA_INTEGER."""
     rc = np.asarray(revCond)
@@ -296,8 +312,7 @@ def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_o
     Goes through the C symbol gpv_U_NZentries exactly as the R .C() binding would."""
     locs = np.asfortranarray(locs, dtype=np.float64)
     Nlocs, dim = locs.shape
-    nn = L.as_r_int_matrix(revNNarray)
-    cd = _cond_to_r(revCondOnLatent)
+    nn, cd = _r_layout_cached(revNNarray, revCondOnLatent)
     p = nn.shape[1]
     nug = np.ascontiguousarray(nuggets, dtype=np.float64)
     nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)

@@ -102,11 +102,11 @@ int cov_setup(const char *covType, const double *cp, int ncov, CovSetup &c)
 }
 
 template <class F>
-void parallel_for(int64_t n, F f)
+void parallel_for(int64_t n, F f, int max_threads = 32)
 {
     unsigned hw = std::thread::hardware_concurrency();
     int64_t nt = hw ? hw : 4;
-    if (nt > 32) nt = 32;
+    if (nt > max_threads) nt = max_threads;
     if (n < 65536) nt = 1;
     if (nt <= 1) {
         f(0, n);
@@ -252,6 +252,8 @@ struct gpv_plan {
     unsigned *d_ticket = nullptr;                    // arrival counter of the set kernel's workgroups (gpv_reduce_tail.hpp)
     // pinned host mirror of the totals: when the caller names no device mirror, the kernels write the totals straight into
     // host memory and gpv_plan_get_sums needs no copy command, only the stream's completion
+    void *h_stage[2] = {nullptr, nullptr};           // pinned staging of gpv_plan_get_Lentries (32 MB each, on first use)
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
     double *h_sums = nullptr, *h_sums_dev = nullptr;
     bool sums_on_host = false;
     // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
@@ -370,6 +372,10 @@ int gpv_plan_destroy(gpv_plan *pl)
     for (int t = 0; t < 2; ++t) {
         if (pl->h_mt2[t]) (void)hipHostFree(pl->h_mt2[t]);
         if (pl->mt_ev[t]) (void)hipEventDestroy(pl->mt_ev[t]);
+    }
+    for (int b = 0; b < 2; ++b) {
+        if (pl->h_stage[b]) (void)hipHostFree(pl->h_stage[b]);
+        if (pl->stage_ev[b]) (void)hipEventDestroy(pl->stage_ev[b]);
     }
     if (pl->h_sums) (void)hipHostFree(pl->h_sums);
     if (pl->h_vl) (void)hipHostFree(pl->h_vl);
@@ -1483,9 +1489,40 @@ int gpv_plan_get_Lentries(gpv_plan *pl, double *Lentries)
     GPV_HIP(hipSetDevice(pl->device));
     const size_t bytes = sizeof(double) * (size_t)pl->rows * pl->p;
     if (!pl->d_tmp) GPV_HIP(hipMalloc((void **)&pl->d_tmp, bytes));
-    GPV_HIP(launch_rows_to_colmajor(pl->d_L, pl->P, pl->rows, pl->p, pl->d_tmp, pl->last_stream));
-    GPV_HIP(hipMemcpyAsync(Lentries, pl->d_tmp, bytes, hipMemcpyDeviceToHost, pl->last_stream));
-    GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    hipStream_t st = pl->last_stream;
+    GPV_HIP(launch_rows_to_colmajor(pl->d_L, pl->P, pl->rows, pl->p, pl->d_tmp, st));
+    static const bool no_stage = getenv("GPV_NO_D2H_STAGING") != nullptr;
+    constexpr size_t kChunk = (size_t)32 << 20;
+    if (no_stage || bytes < 2 * kChunk) {
+        GPV_HIP(hipMemcpyAsync(Lentries, pl->d_tmp, bytes, hipMemcpyDeviceToHost, st));
+        GPV_HIP(hipStreamSynchronize(st));
+        return GPV_OK;
+    }
+    // The caller's buffer is pageable (R allocates a fresh vector per .C() call): a plain hipMemcpy of 248 MB moves at
+    // ~27 GB/s through HIP's own staging.  Two pinned 32 MB buffers instead: chunk c travels by DMA while host threads
+    // copy chunk c - 1 out of the other buffer into the caller's memory.
+    for (int b = 0; b < 2; ++b) {
+        if (!pl->h_stage[b]) GPV_HIP(hipHostMalloc((void **)&pl->h_stage[b], kChunk, hipHostMallocDefault));
+        if (!pl->stage_ev[b]) GPV_HIP(hipEventCreateWithFlags(&pl->stage_ev[b], hipEventDisableTiming));
+    }
+    const size_t nchunk = (bytes + kChunk - 1) / kChunk;
+    const char *src = reinterpret_cast<const char *>(pl->d_tmp);
+    char *dst = reinterpret_cast<char *>(Lentries);
+    auto issue = [&](size_t c) -> hipError_t {
+        const size_t off = c * kChunk, len = (off + kChunk <= bytes) ? kChunk : bytes - off;
+        hipError_t e = hipMemcpyAsync(pl->h_stage[c & 1], src + off, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(pl->stage_ev[c & 1], st);
+        return e;
+    };
+    GPV_HIP(issue(0));
+    if (nchunk > 1) GPV_HIP(issue(1));
+    for (size_t c = 0; c < nchunk; ++c) {
+        GPV_HIP(hipEventSynchronize(pl->stage_ev[c & 1]));
+        const size_t off = c * kChunk, len = (off + kChunk <= bytes) ? kChunk : bytes - off;
+        const char *hs = reinterpret_cast<const char *>(pl->h_stage[c & 1]);
+        parallel_for((int64_t)len, [=](int64_t b0, int64_t e0) { std::memcpy(dst + off + b0, hs + b0, (size_t)(e0 - b0)); }, 8);
+        if (c + 2 < nchunk) GPV_HIP(issue(c + 2));
+    }
     return GPV_OK;
 }
 
