@@ -76,6 +76,9 @@
 #ifndef GPV_OPT_FREEZE
 #define GPV_OPT_FREEZE 1      // DPP sweep: row slots whose pivots are all done stop taking part; their last column is completed by a
 #endif                        // block back-substitution after the sweep (P = 31: 14 FMAs instead of 105 + 14 multipliers)
+#ifndef GPV_OPT_GEN_SGPR
+#define GPV_OPT_GEN_SGPR 1    // general nu: exp's Horner coefficients in SGPRs (no v_mov + v_fmac pairs)
+#endif
 #ifndef GPV_PFREC_AT
 #define GPV_PFREC_AT(P) ((P) / 2)   // sweep pivot at which the next task's location records are requested
 #endif
@@ -417,6 +420,16 @@ __device__ __forceinline__ double sgpr_f64(double x)
     const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
     return __hiloint2double(hi, lo);
 }
+// x as a value the compiler can no longer see through, held in an SGPR pair: a Horner step on it must be the three-address
+// v_fma_f64 (a VOP2 v_fmac cannot take an SGPR addend), where on register-resident or literal coefficients hipcc may choose
+// v_mov_b64 + v_fmac_f64 -- two issue slots per step (seen in the general-nu kernel: +9 instructions per pair)
+__device__ __forceinline__ double sgpr_opaque(const double x)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    return __hiloint2double(hi, lo);
+}
+template <bool OPAQUE = false>
 __device__ __forceinline__ ExpScaled exp_scaled_setup(const double scale)
 {
     constexpr double k[10] = {0x1.af631d0059becp-26, 0x1.28b4057f44145p-22, 0x1.71ddf5749d126p-19, 0x1.a01991ac8730ap-16,
@@ -424,7 +437,7 @@ __device__ __forceinline__ ExpScaled exp_scaled_setup(const double scale)
                               0x1.555555555555ap-3,  0x1.0000000000011p-1};
     ExpScaled E;
 #pragma unroll
-    for (int i = 0; i < 10; ++i) E.c[i] = sgpr_f64(k[i] * scale);
+    for (int i = 0; i < 10; ++i) E.c[i] = OPAQUE ? sgpr_opaque(k[i] * scale) : sgpr_f64(k[i] * scale);
     E.c[10] = E.c[11] = sgpr_f64(scale);
     return E;
 }
@@ -648,7 +661,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 
     const double sig0 = A.sig0, sA = A.sA, cA = A.cA, sB = A.sB, cB = A.cB;
     // closed-form Matern families: sigma^2 exp(-t) (cov_closed); general nu: the table carries the constant factor
-    const ExpScaled expS = exp_scaled_setup(COV == COV_MATERN_GEN ? 1.0 : sA);
+    const ExpScaled expS = exp_scaled_setup<(COV == COV_MATERN_GEN && GPV_OPT_GEN_SGPR != 0)>(COV == COV_MATERN_GEN ? 1.0 : sA);
     const unsigned long long setmask = (LPS == 64) ? ~0ull : (((1ull << LPS) - 1ull) << (sub * LPS));
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
