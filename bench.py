@@ -275,7 +275,8 @@ def per_rank_step(args, emulate=8, steps=200):
     a real all-reduce adds its xGMI round."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", "20",
-           "--emulate-world", str(emulate), "--no-cpu-baseline", "--no-secondary", "--config", args.config]
+           "--emulate-world", str(emulate), "--no-cpu-baseline", "--no-secondary", "--config", args.config,
+           "--clock-warmup-s", str(args.clock_warmup_s)]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
@@ -289,8 +290,9 @@ def per_rank_step(args, emulate=8, steps=200):
     return {"ms_per_step": j["ms_per_step"], "kernel_ms": k_ms, "overhead_us": 1e3 * (j["ms_per_step"] - k_ms),
             "rows": j["roofline"]["sets_per_launch"], "emulated_world": emulate, "backend": "nccl (RCCL), world 1",
             "what": "emulated per-rank load, not a scaling number: one GPU takes rank 0's shard of an 8-rank job and runs the "
-                    "step of the N > 1 path (kernel with fused reduction, RCCL all_reduce of 8 doubles, pinned copy, polled "
-                    "event); overhead_us = ms_per_step - kernel_ms is the fixed cost strong scaling pays per step"}
+                    "step of the N > 1 path (kernel with fused reduction, the library's own RCCL all-reduce of 8 doubles on "
+                    "the same stream, 64-thread kernel that stores them into pinned memory behind a sequence number the host "
+                    "spins on); overhead_us = ms_per_step - kernel_ms is the fixed cost strong scaling pays per step"}
 
 
 def main():
@@ -313,6 +315,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the mode U / mode S secondary measurements")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0,
                     help="per-repeat wall budget of the CPU baseline; the whole data set is timed when it fits")
+    ap.add_argument("--clock-warmup-s", type=float, default=0.1,
+                    help="seconds of untimed evaluations before the W warm-up steps of every measurement, so that the timed steps "
+                         "run at the steady shader clock (0 = none; reported in the JSON line)")
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="developer/secondary measurement: this rank takes the row shard rank 0 of a job of that many ranks "
                          "would own (rows = n / E) while the collectives run over the real world; NOT a scaling number")
@@ -363,6 +368,13 @@ def main():
 
     import gpvecchia_amd as G
 
+    # the collective of the step belongs to the library (gpv_comm: RCCL bound at run time, include/gpvecchia.h); torch.distributed
+    # is the launcher, the rendezvous that carries the communicator's id, and the barrier / max-over-ranks of the timing.
+    # GPV_TORCH_ALLREDUCE=1: the round-2 route (dist.all_reduce on the plan's device buffer), kept for A/B
+    comm = None
+    if use_dist and backend == "nccl" and os.environ.get("GPV_TORCH_ALLREDUCE", "0") != "1" and args.mode != "S":
+        comm = G.Comm.from_torch(local_rank)
+
     ci, n, m, d, nu, rng_ = CONFIGS[args.config]
     custom = any(v is not None for v in (args.n, args.m, args.d, args.nu))
     n = args.n or n
@@ -399,32 +411,68 @@ def main():
     def measure_with(plan, flags, denom, steps, warmup, covparms, tau, n):
         """W untimed + K timed evaluations of `plan`; returns (seconds, mean set-kernel ms, loglik)."""
         def step():
+            if comm is not None:
+                # N > 1 (one process per GPU): the library enqueues kernel, RCCL all-reduce of the 8 sums (64 bytes over xGMI)
+                # and their copy to pinned host memory on this one stream; sums() spins on the event behind the copy
+                plan.eval("matern", covparms, tau, flags, stream=stream)
+                host = plan.sums()
+                return G.loglik_z_from_sums(host, n)
             if use_dist:
                 plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
                 all_reduce_(sums, dist.ReduceOp.SUM)              # the ONE collective: 64 bytes over xGMI
                 # the 8 sums reach the host through a pinned buffer: copy on the launch stream, then poll that stream's event
                 pinned.copy_(sums, non_blocking=True)
+                done.record(tstream)
+                while not done.query():                           # spin on the event's flag: no interrupt-driven wake-up
+                    pass
+                host = pinned.numpy()
             else:
-                # one GPU: the kernel that totals the sums writes them straight into the pinned host buffer (device-visible
-                # host memory): no copy command between the kernel and the host
-                plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=pinned.data_ptr())
-            done.record(tstream)
-            while not done.query():                               # spin on the event's flag: no interrupt-driven wake-up
-                pass
-            host = pinned.numpy()
+                # one GPU: exactly what vecchia_likelihood() does.  The kernel that totals the sums stores them into the plan's
+                # pinned host buffer followed by the evaluation's sequence number; sums() spins on that number (posterior pass:
+                # waits for the stream)
+                plan.eval("matern", covparms, tau, flags, stream=stream)
+                host = plan.sums()
             return G.loglik_from_sums(host, n) if denom else G.loglik_z_from_sums(host, n)
         ll = None
+        # clock warm-up (untimed, before the W warm-up steps): the GPU's power management drops the shader clock within
+        # milliseconds of idling and takes ~35 ms of continuous work to bring it back (tools/clock_ramp.py,
+        # profiles/r03_clock_ramp.txt: 1.46 -> 1.26 ms per launch over the first 25 launches at this workload); a timed region of 20
+        # steps behind 5 warm-up steps would measure the ramp, not the rate an optimiser loop sees
+        if args.clock_warmup_s > 0:
+            t_w = time.perf_counter()
+            for _ in range(3):
+                step()
+            cnt = int(min(5000.0, args.clock_warmup_s / max((time.perf_counter() - t_w) / 3, 1e-5))) + 1
+            if use_dist:                                          # every rank runs the same number of collectives
+                tc = torch.tensor([cnt], dtype=torch.int64, device="cuda")
+                all_reduce_(tc, dist.ReduceOp.MAX)
+                cnt = int(tc.item())
+            for _ in range(cnt):
+                step()
         for _ in range(warmup):
             ll = step()
         kms = []
+        # like timeit: no cyclic-GC pass inside the timed region (with torch imported a full collection walks millions of
+        # objects: one 55 ms pause was seen in a 70 ms region of 0.18 ms steps; tools/comm_diag.py)
+        import gc
+        gc.collect()
+        gc.disable()
         fence()
         t0 = time.perf_counter()
+        trace = [] if os.environ.get("GPV_BENCH_TRACE") else None
         for _ in range(steps):
             ll = step()
             if plan.kernel_timing:
                 kms.append(plan.last_kernel_ms())                # hipEvent pair on the launch stream, already complete
+            if trace is not None:
+                trace.append(time.perf_counter())
+        if trace:
+            dt = 1e6 * np.diff(np.array([t0] + trace))
+            print(f"[bench trace] steps {steps}: median {np.median(dt):.1f} us, mean {dt.mean():.1f}, max {dt.max():.1f}, "
+                  f"over 2x median: {int((dt > 2 * np.median(dt)).sum())}; first 5: {np.round(dt[:5], 1)}", file=sys.stderr)
         fence()
         el = time.perf_counter() - t0
+        gc.enable()
         return el, (float(np.mean(kms)) if kms else float("nan")), ll
 
     def roofline(k_ms, rows_rank, mode, traffic=None):
@@ -459,6 +507,8 @@ def main():
             locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, device=local_rank)
         plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
         plan.set_data(z)
+        if comm is not None:
+            plan.set_comm(comm)
         flags, denom = G.GPV_WANT_LOGLIK_Z | (G.GPV_WANT_U if args.mode == "U" else 0), False
     t_setup = time.time() - t_setup
 
@@ -517,6 +567,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
+            "clock_warmup_s": args.clock_warmup_s,           # untimed evaluations before the W warm-up steps (see measure_with)
             "config": {"workload": f"n={n} {d}-D uniform, Matern nu={nu}, m={m}, ordering={ord_s}, cond.yz={cond_s}, "
                                    f"mode {args.mode} (" + ("custom sizes" if custom else f"BASELINE.json configs[{ci}]")
                                    + (f"; rows sharded over {world} GPU(s))" if args.emulate_world == 1 else

@@ -37,6 +37,7 @@ EXPORTS = [
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
     "gpv_mplan_create_replicas", "gpv_mplan_count", "gpv_mplan_set_data_one", "gpv_mplan_build_posterior",
     "gpv_mplan_eval_each", "gpv_mplan_vl_begin_one", "gpv_mplan_vl_step_each", "gpv_mplan_vl_get_one",
+    "gpv_comm_unique_id", "gpv_comm_create", "gpv_comm_destroy", "gpv_plan_set_comm",
 ]
 
 
@@ -110,6 +111,10 @@ def lib():
     L.gpv_mplan_vl_begin_one.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
     L.gpv_mplan_vl_step_each.argtypes = [vp, C.c_char_p, dp, C.c_int, ip, dp, ip]
     L.gpv_mplan_vl_get_one.argtypes = [vp, C.c_int, dp, dp, dp]
+    L.gpv_comm_unique_id.argtypes = [vp]
+    L.gpv_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
+    L.gpv_comm_destroy.argtypes = [vp]
+    L.gpv_plan_set_comm.argtypes = [vp, vp]
     L.gpv_order_maxmin_exact.argtypes = [dp, i64, C.c_int, ip]
     L.gpv_ic0.argtypes = [i64, ip, ip, dp, C.POINTER(C.c_int64)]
     L.gpv_find_ordered_nn.argtypes = [C.c_int, dp, i64, C.c_int, C.c_int, i64, i64, ip]

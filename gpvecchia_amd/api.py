@@ -154,6 +154,47 @@ class Plan:
         L.check(L.lib().gpv_plan_last_kernel_ms(self._h, C.byref(ms)), "gpv_plan_last_kernel_ms")
         return float(ms.value)
 
+    def set_comm(self, comm):
+        """Attach (or, with None, detach) a Comm: every eval() then all-reduces its 8 sums over the ranks, inside the library."""
+        L.check(L.lib().gpv_plan_set_comm(self._h, comm._h if comm is not None else None), "gpv_plan_set_comm")
+        self._comm = comm                                     # keeps the communicator alive as long as the plan uses it
+
+
+class Comm:
+    """gpv_comm: an RCCL communicator owned by the library (one process per GPU).  `exchange(id_bytes_or_None) -> id_bytes`
+    carries rank 0's 128-byte id to the other ranks (from_torch() does it over an initialised torch.distributed group)."""
+
+    def __init__(self, device, rank, world, exchange):
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            L.check(L.lib().gpv_comm_unique_id(ident), "gpv_comm_unique_id")
+        raw = exchange(bytes(ident.raw) if rank == 0 else None)
+        if not isinstance(raw, (bytes, bytearray)) or len(raw) != 128:
+            raise ValueError("Comm: the exchange must hand every rank the 128 bytes of rank 0")
+        ident = C.create_string_buffer(bytes(raw), 128)
+        self._h = C.c_void_p()
+        self.device, self.rank, self.world = int(device), int(rank), int(world)
+        L.check(L.lib().gpv_comm_create(C.byref(self._h), self.device, self.rank, self.world, ident), "gpv_comm_create")
+
+    @classmethod
+    def from_torch(cls, device, group=None):
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def exchange(mine):
+            box = [mine]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            return box[0]
+        return cls(device, rank, world, exchange)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value:
+                L.lib().gpv_comm_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
 
 class MultiPlan:
     """gpv_mplan: the same vecchia.approx spread over several GPUs of one host process (row shards)."""

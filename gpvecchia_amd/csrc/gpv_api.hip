@@ -8,6 +8,8 @@
 #include "gpv_generic.h"
 #include "gpv_posterior_ext.h"
 
+#include <dlfcn.h>
+
 #include <cstdio>
 #include <chrono>
 #include <climits>
@@ -16,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -44,6 +47,55 @@ inline int note_hip(hipError_t e, const char *what, int line)
     } while (0)
 // the same for code that cleans up before it returns: evaluates to true on failure
 #define GPV_HIP_FAILED(expr) ([&]() { hipError_t e_ = (expr); if (e_ != hipSuccess) { note_hip(e_, #expr, __LINE__); return true; } return false; }())
+
+// RCCL is bound at run time (dlopen), never at link time: the library must load in an R session on a one-GPU machine that has
+// no RCCL at all.  Only five entry points are used; their C ABI (rccl.h: 128-byte ncclUniqueId by value, ncclDouble = 8,
+// ncclSum = 0) has been stable since NCCL 2.0.
+namespace {
+struct RcclId { char internal[128]; };
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+thread_local char g_rccl_text[200] = "";
+const RcclApi *rccl_api()
+{
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a process that already holds RCCL (PyTorch loads its own copy) is given THAT copy: dlopen matches the soname
+        const char *names[] = {getenv("GPV_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) {
+            if (!nm || !*nm) continue;
+            if ((api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+        }
+        if (!api.handle) return;
+        api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
+        api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
+        api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
+        api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
+        api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { dlclose(api.handle); api = RcclApi{}; }
+    });
+    return api.handle ? &api : nullptr;
+}
+inline int note_rccl(int r, const char *what)
+{
+    const RcclApi *A = rccl_api();
+    g_hip_code = r;
+    std::snprintf(g_hip_text, sizeof(g_hip_text), "RCCL: %s [%s]", (A && A->GetErrorString) ? A->GetErrorString(r) : "?", what);
+    return GPV_ERR_HIP;
+}
+}  // namespace
+
+struct gpv_comm {
+    void *comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+};
 
 namespace {
 
@@ -256,6 +308,11 @@ struct gpv_plan {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     double *h_sums = nullptr, *h_sums_dev = nullptr;
     bool sums_on_host = false;
+    // hand-off of the totals by memory: h_sums holds 8 totals and, behind them, 8 sequence numbers the producing kernel
+    // stores after the totals (gpv_reduce_tail.hpp, publish_seq); gpv_plan_get_sums spins on them
+    unsigned long long seq = 0;                      // sequence number of the latest evaluation
+    bool sums_by_seq = false;                        // the latest evaluation publishes its totals that way
+    gpv_comm *comm = nullptr;                        // attached communicator: every evaluation all-reduces its 8 sums (gpv_plan_set_comm)
     // posterior ("U2V") pass, built on request (gpv_plan_build_posterior)
     bool have_post = false;
     int32_t *d_colptr = nullptr, *d_crow = nullptr;
@@ -613,9 +670,10 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
     if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_sums, sizeof(double) * kNSums))) return fail(GPV_ERR_HIP);
     if (GPV_HIP_FAILED(hipMalloc((void **)&pl->d_ticket, 64)) || GPV_HIP_FAILED(hipMemset(pl->d_ticket, 0, 64)))
         return fail(GPV_ERR_HIP);
-    if (GPV_HIP_FAILED(hipHostMalloc((void **)&pl->h_sums, sizeof(double) * kNSums, hipHostMallocDefault)) ||
+    if (GPV_HIP_FAILED(hipHostMalloc((void **)&pl->h_sums, sizeof(double) * 2 * kNSums, hipHostMallocDefault)) ||
         GPV_HIP_FAILED(hipHostGetDevicePointer((void **)&pl->h_sums_dev, pl->h_sums, 0)))
         return fail(GPV_ERR_HIP);
+    std::memset(pl->h_sums, 0, sizeof(double) * 2 * kNSums);
     if (GPV_HIP_FAILED(hipMemcpy(pl->d_nn, nn.data(), nnb, hipMemcpyHostToDevice))) return fail(GPV_ERR_HIP);
     if (GPV_HIP_FAILED(hipMemcpy(pl->d_cond, cd.data(), cdb, hipMemcpyHostToDevice))) return fail(GPV_ERR_HIP);
     if (GPV_HIP_FAILED(hipMemcpy(pl->d_locs, lr.data(), lrb, hipMemcpyHostToDevice))) return fail(GPV_ERR_HIP);
@@ -703,10 +761,23 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.aout = (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) ? pl->d_avec : nullptr;
     a.block_sums = pl->d_block;
     a.sums = pl->d_sums;
-    double *const mirror = d_sums_out ? d_sums_out : pl->h_sums_dev;
+    // with a communicator attached the totals of THIS rank stay in d_sums, RCCL sums them over the ranks in place on the
+    // same stream, and one 64-byte copy command hands them to the host (or to the caller's device buffer)
+    gpv_comm *const cm = pl->comm;
+    if (cm && (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B))) return GPV_ERR_STATE;   // the posterior pass does not shard
+    double *const mirror = cm ? nullptr : (d_sums_out ? d_sums_out : pl->h_sums_dev);
     pl->sums_on_host = (d_sums_out == nullptr);
     a.sums_copy = mirror;
     a.ticket = pl->d_ticket;
+    // the set kernel's totals are final (no posterior pass adds to them) and go to the plan's own host buffer: the kernel
+    // appends the sequence number of this evaluation and gpv_plan_get_sums spins on it instead of waiting for the stream
+    static const bool no_seq = getenv("GPV_NO_SEQ_HANDOFF") != nullptr;
+    unsigned long long *const seq_cells = reinterpret_cast<unsigned long long *>(pl->h_sums_dev + kNSums);
+    const bool final_here = !(flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) && d_sums_out == nullptr && !no_seq;
+    pl->sums_by_seq = final_here;
+    if (final_here) ++pl->seq;
+    a.seq_cells = (final_here && !cm) ? seq_cells : nullptr;
+    a.seq = pl->seq;
     a.nug_cell = (flags & GPV_WANT_DENOM) ? pl->d_nug_post : nullptr;
     a.rows = pl->rows;
     a.nlocs = pl->Nlocs;
@@ -782,6 +853,21 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         pl->mt_pending = -1;
     }
     // (the partial sums are totalled by the set kernel's last workgroup: no reduction launch)
+    if (cm) {
+        const RcclApi *R = rccl_api();
+        if (!R) return GPV_ERR_STATE;
+        const int rr = R->AllReduce(pl->d_sums, pl->d_sums, (size_t)kNSums, /*ncclDouble*/ 8, /*ncclSum*/ 0, cm->comm, st);
+        if (rr != 0) return note_rccl(rr, "ncclAllReduce");
+        // to the host by a 64-thread kernel that stores into pinned memory, not by a copy command: an event behind a 64-byte
+        // hipMemcpyAsync took ~100 us longer to turn ready under hipEventQuery (measured, tools/comm_diag.py)
+        if (d_sums_out) {
+            GPV_HIP(hipMemcpyAsync(d_sums_out, pl->d_sums, sizeof(double) * kNSums, hipMemcpyDeviceToDevice, st));
+        } else if (pl->sums_by_seq) {
+            GPV_HIP(launch_publish_sums(pl->d_sums, pl->h_sums_dev, seq_cells, pl->seq, st));
+        } else {
+            GPV_HIP(hipMemcpyAsync(pl->h_sums, pl->d_sums, sizeof(double) * kNSums, hipMemcpyDeviceToHost, st));
+        }
+    }
     if (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) {
         // (constant nugget: the set kernel above left it in d_nug_post[0]; vector: d_nug_user, a fixed address as well)
         PostArgs pa;
@@ -871,6 +957,60 @@ int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int
     const int st = cov_setup(covType, covparms, ncovparms, cs);
     if (st != GPV_OK) return st;
     return plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
+}
+
+int gpv_comm_unique_id(void *id128)
+{
+    if (!id128) return GPV_ERR_BAD_ARG;
+    const RcclApi *R = rccl_api();
+    if (!R) return GPV_ERR_STATE;
+    RcclId id;
+    const int rr = R->GetUniqueId(&id);
+    if (rr != 0) return note_rccl(rr, "ncclGetUniqueId");
+    std::memcpy(id128, &id, sizeof(id));
+    return GPV_OK;
+}
+
+int gpv_comm_create(gpv_comm **out, int device, int rank, int world, const void *id128)
+{
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return GPV_ERR_BAD_ARG;
+    *out = nullptr;
+    const RcclApi *R = rccl_api();
+    if (!R) return GPV_ERR_STATE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GPV_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return GPV_ERR_BAD_ARG;
+    GPV_HIP(hipSetDevice(device));                 // RCCL binds the communicator to the CURRENT device
+    RcclId id;
+    std::memcpy(&id, id128, sizeof(id));
+    void *c = nullptr;
+    const int rr = R->CommInitRank(&c, world, id, rank);   // collective: returns when every rank has joined
+    if (rr != 0 || !c) return note_rccl(rr, "ncclCommInitRank");
+    gpv_comm *cm = new gpv_comm;
+    cm->comm = c; cm->device = device; cm->rank = rank; cm->world = world;
+    *out = cm;
+    return GPV_OK;
+}
+
+int gpv_comm_destroy(gpv_comm *cm)
+{
+    if (!cm) return GPV_OK;
+    const RcclApi *R = rccl_api();
+    if (R && cm->comm) {
+        (void)hipSetDevice(cm->device);
+        (void)R->CommDestroy(cm->comm);
+    }
+    delete cm;
+    return GPV_OK;
+}
+
+int gpv_plan_set_comm(gpv_plan *pl, gpv_comm *cm)
+{
+    if (!pl) return GPV_ERR_BAD_ARG;
+    if (cm && cm->device != pl->device) return GPV_ERR_BAD_ARG;
+    if (pl->last_stream) { GPV_HIP(hipSetDevice(pl->device)); GPV_HIP(hipStreamSynchronize(pl->last_stream)); }
+    pl->comm = cm;
+    return GPV_OK;
 }
 
 static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCond, bool with_fill, double max_fill,
@@ -1472,7 +1612,24 @@ int gpv_plan_get_sums(gpv_plan *pl, double *sums)
     if (!pl->evaluated) return GPV_ERR_STATE;
     GPV_HIP(hipSetDevice(pl->device));
     if (pl->sums_on_host) {                        // the kernels wrote the totals into pinned host memory
-        GPV_HIP(hipStreamSynchronize(pl->last_stream));
+        if (pl->sums_by_seq) {
+            // spin on the sequence numbers the producing kernel stores behind the totals: no stream wait, no wake-up by
+            // interrupt (the evaluation is a fraction of a millisecond for one rank of a sharded job).  Every 64 Ki spins the
+            // stream is asked whether it has failed or finished without the numbers turning up (then the ordinary wait decides).
+            const volatile unsigned long long *c = reinterpret_cast<const volatile unsigned long long *>(pl->h_sums + kNSums);
+            bool seen = false;
+            for (unsigned spin = 1; !seen; ++spin) {
+                seen = true;
+                for (int t = 0; t < kNSums; ++t) seen = seen && (c[t] == pl->seq);
+                if (seen) break;
+                __builtin_ia32_pause();                  // be a polite spinner: the sibling hardware thread may be the runtime's
+                if ((spin & 0xFFFFu) == 0 && hipStreamQuery(pl->last_stream) != hipErrorNotReady) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (!seen) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+        } else {
+            GPV_HIP(hipStreamSynchronize(pl->last_stream));
+        }
         std::memcpy(sums, pl->h_sums, sizeof(double) * kNSums);
         return GPV_OK;
     }

@@ -42,6 +42,21 @@ hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStrea
     }
 }
 
+__global__ void __launch_bounds__(64) gpv_publish_sums_kernel(const double *sums, double *host_sums, unsigned long long *seq_cells,
+                                                              unsigned long long seq)
+{
+    if (threadIdx.x < kNSums) {
+        host_sums[threadIdx.x] = sums[threadIdx.x];
+        publish_seq(seq_cells + threadIdx.x, seq);
+    }
+}
+hipError_t launch_publish_sums(const double *sums, double *host_sums, unsigned long long *seq_cells, unsigned long long seq,
+                               hipStream_t s)
+{
+    hipLaunchKernelGGL(gpv_publish_sums_kernel, dim3(1), dim3(64), 0, s, sums, host_sums, seq_cells, seq);
+    return hipGetLastError();
+}
+
 __global__ void gpv_fill_kernel(double *dst, double value, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

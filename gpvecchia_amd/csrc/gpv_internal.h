@@ -32,6 +32,8 @@ struct SetArgs {
     double *sums;            // [kNSums] their fixed-order total, written by the workgroup that finishes last (gpv_reduce_tail.hpp)
     double *sums_copy;       // second destination of the totals (the caller's all-reduce buffer) or nullptr
     unsigned *ticket;        // arrival counter of the launch's workgroups; zero between launches
+    unsigned long long *seq_cells;   // [kNSums] in host memory next to a host sums_copy: each total is followed (system-scope release)
+    unsigned long long seq;          //   by the evaluation's sequence number, which the host spins on; nullptr: no hand-off by memory
     double *nug_cell;        // where the posterior pass reads the constant nugget from (PostArgs::nug_cell), or nullptr
     int64_t rows;            // conditioning sets in this launch
     int64_t nlocs;
@@ -56,6 +58,10 @@ hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStrea
 // smallest compiled P >= p, or 0
 int pick_P(int p);
 int max_P();
+
+// the 8 totals in `sums` (device) -> host memory with the sequence-number hand-off of SetArgs::seq_cells (one 64-thread launch)
+hipError_t launch_publish_sums(const double *sums, double *host_sums, unsigned long long *seq_cells, unsigned long long seq,
+                               hipStream_t s);
 
 // small helper kernels (gpv_aux_kernels.hip)
 hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);

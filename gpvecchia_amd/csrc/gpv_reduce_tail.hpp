@@ -11,6 +11,17 @@
 
 namespace gpv {
 
+// Hand-off of a value this thread has just stored to HOST memory: its sequence number follows it with a system-scope release,
+// so a host thread that reads the number (and then an acquire fence) reads the value.  The host spins on the number instead
+// of waiting for the stream: no completion signal, no interrupt, no runtime call between the last store and the reader.
+__device__ __forceinline__ void publish_seq(unsigned long long *cell, unsigned long long seq)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(cell, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Call from every thread of the workgroup; threads 0..kNSums-1 (wave 0) hold this workgroup's partial sums in `mine`.
 // NT = threads per workgroup (a multiple of 64, at most 256).  s_part (NT doubles) and s_last_p (one int) are LDS the
 // workgroup no longer uses (the caller has passed a workgroup barrier since their last use): the kernels run at the edge of
@@ -61,6 +72,7 @@ __device__ __forceinline__ void reduce_tail(const SetArgs &A, double mine, doubl
         for (int p2 = 0; p2 < NP; ++p2) t += s_part[p2 * kNSums + threadIdx.x];
         A.sums[threadIdx.x] = t;
         if (A.sums_copy != nullptr) A.sums_copy[threadIdx.x] = t;
+        if (A.seq_cells != nullptr) publish_seq(A.seq_cells + threadIdx.x, A.seq);
         if (threadIdx.x == 0) {
             *A.ticket = 0u;                              // for the next launch (ordered behind this one by its stream)
             if (A.nug_cell != nullptr) *A.nug_cell = A.nug_scalar;

@@ -46,9 +46,10 @@ class ShardedLikelihood:
     GPU box; the CPU tests inject a stand-in that computes its shard's sums with the oracle).
 
     With the "nccl" (= RCCL) backend the rank is bound to ONE GPU: `device` (default: the plan's device, else
-    LOCAL_RANK).  The evaluation, the all-reduce of the 8 partial sums and their copy to a pinned host buffer are
-    enqueued on one private stream; the device buffer the kernel deposits its sums in is the buffer RCCL reduces
-    (no host round trip before the collective, no per-evaluation allocation)."""
+    LOCAL_RANK).  The library itself owns an RCCL communicator (api.Comm; its id travels over the torch group once) and
+    enqueues the all-reduce of the 8 partial sums and their 64-byte copy to pinned host memory on the evaluation's own
+    stream right behind the kernel: torch.distributed is the launcher and the rendezvous, not part of the step.
+    GPV_TORCH_ALLREDUCE=1 selects the older route (dist.all_reduce on the plan's device buffer) instead."""
 
     def __init__(self, n_rows, z_ord, plan_factory, rank=None, world=None, group=None, device=None):
         import torch.distributed as dist
@@ -74,6 +75,11 @@ class ShardedLikelihood:
             if pdev != device:
                 raise ValueError(f"rank {rank}: plan lives on GPU {pdev} but the rank is bound to GPU {device}")
             self.device = device
+            self._native = os.environ.get("GPV_TORCH_ALLREDUCE", "0") != "1" and hasattr(self.plan, "set_comm")
+            if self._native:
+                from .api import Comm
+                self._comm = Comm.from_torch(device, group)
+                self.plan.set_comm(self._comm)
             self._stream = torch.cuda.Stream(device=device)
             self._d = torch.zeros(NSUMS, dtype=torch.float64, device=f"cuda:{device}")
             self._h = torch.zeros(NSUMS, dtype=torch.float64).pin_memory()
@@ -81,6 +87,9 @@ class ShardedLikelihood:
         self.plan.set_data(z_ord)
 
     def sums(self, covmodel, covparms, nuggets, flags):
+        if self._nccl and self._native:
+            self.plan.eval(covmodel, covparms, nuggets, flags, stream=self._stream.cuda_stream)
+            return np.asarray(self.plan.sums(), dtype=np.float64)     # totals of the whole job (polled, not slept on)
         if self._nccl:
             import torch
             import torch.distributed as dist

@@ -296,6 +296,25 @@ int gpv_mplan_vl_step_each(gpv_mplan *mplan, const char *covType, const double *
 int gpv_mplan_vl_get_one(gpv_mplan *mplan, int replica, double *mean_ord, double *t_ord, double *D_ord);
 
 /* -------------------------------------------------------------------------
+ * Several GPUs, ONE PROCESS PER GPU (an MPI-style launch, or torch.distributed.run): each rank creates a plan
+ * for its own contiguous block of rows (row_begin / row_end of gpv_plan_create; src/U_NZentries.cpp:37-39: rows never
+ * read or write each other) and attaches a communicator.  Every gpv_plan_eval of that plan then sums the GPV_NSUMS
+ * partial sums over the ranks with ONE RCCL all-reduce (64 bytes over xGMI), enqueued by the library on the evaluation's
+ * own stream right behind the kernel -- no second stream, no event hop, no framework in between -- and gpv_plan_get_sums
+ * returns the totals of the WHOLE job on every rank.  RCCL is bound at run time (dlopen of librccl.so.1; GPV_RCCL_LIB
+ * names another file): without it these three entries return GPV_ERR_STATE and the rest of the library is unaffected.
+ *   id128: 128 bytes (ncclUniqueId); rank 0 fills it with gpv_comm_unique_id and hands it to the other ranks by whatever
+ *          channel the launcher offers (MPI_Bcast, a torch.distributed store, a file);
+ *   gpv_comm_create is collective: it returns when all `world` ranks have called it with the same id;
+ *   gpv_plan_set_comm(plan, NULL) detaches.  Flags with a communicator: GPV_WANT_U | GPV_WANT_LOGLIK_Z |
+ *   GPV_WANT_NUMERATOR (the posterior pass does not shard: GPV_ERR_STATE). */
+typedef struct gpv_comm gpv_comm;
+int gpv_comm_unique_id(void *id128);
+int gpv_comm_create(gpv_comm **comm, int device, int rank, int world, const void *id128);
+int gpv_comm_destroy(gpv_comm *comm);
+int gpv_plan_set_comm(gpv_plan *plan, gpv_comm *comm);
+
+/* -------------------------------------------------------------------------
  * Host-side setup helper (no GPU needed, parameter independent, once per data set).
  * Not part of the reference's FFI: the reference runs this as interpreted R
  * (R/whichCondOnLatent.R:2-26, O(n m^3)); exported so that SGV plans can be built at n = 1e6.

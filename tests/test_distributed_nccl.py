@@ -30,7 +30,49 @@ def _problem():
     return n, locs, z, revNN, revCond, [1.1, 0.07, 1.5], 0.2
 
 
-def test_sharded_likelihood_rccl_world1_in_process():
+def test_library_owned_communicator_world1():
+    """gpv_comm without torch.distributed anywhere: the library binds RCCL itself and all-reduces inside gpv_plan_eval."""
+    import torch
+    import gpvecchia_amd as G
+    n, locs, z, revNN, revCond, cp, tau = _problem()
+    ref = G.Plan(locs, revNN, revCond)
+    ref.set_data(z)
+    ref.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+    s1 = ref.sums()
+    handed = []
+
+    def exchange(mine):
+        handed.append(mine)
+        return mine
+    comm = G.Comm(0, 0, 1, exchange)
+    assert len(handed) == 1 and len(handed[0]) == 128 and any(handed[0])
+    plan = G.Plan(locs, revNN, revCond)
+    plan.set_data(z)
+    plan.set_comm(comm)
+    for _ in range(3):                                              # the buffers and the event are reusable
+        plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+        assert np.array_equal(plan.sums(), s1)
+    st = torch.cuda.Stream()
+    dev = torch.zeros(G._lib.NSUMS, dtype=torch.float64, device="cuda")
+    plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U, stream=st.cuda_stream, d_sums_out=dev.data_ptr())
+    st.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), s1)
+    assert np.array_equal(plan.Lentries(), (ref.eval("matern", cp, tau, G.GPV_WANT_U), ref.Lentries())[1])
+    with pytest.raises(G.GpvError) as e:                            # the posterior pass does not shard
+        plan.eval("matern", cp, tau, G.GPV_WANT_DENOM)
+    assert e.value.status == 7
+    plan.set_comm(None)
+    plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+    assert np.array_equal(plan.sums(), s1)
+    with pytest.raises(ValueError):
+        G.Comm(0, 0, 1, lambda mine: b"short")
+    with pytest.raises(G.GpvError):
+        G.Comm(99, 0, 1, lambda mine: mine)                         # no such device
+
+
+@pytest.mark.parametrize("route", ["library", "torch"])
+def test_sharded_likelihood_rccl_world1_in_process(route, monkeypatch):
+    monkeypatch.setenv("GPV_TORCH_ALLREDUCE", "1" if route == "torch" else "0")
     import torch
     import torch.distributed as dist
     import gpvecchia_amd as G
@@ -46,7 +88,7 @@ def test_sharded_likelihood_rccl_world1_in_process():
                             device_id=torch.device("cuda", 0))
     try:
         sl = ShardedLikelihood(n, z, lambda a, b: G.Plan(locs, revNN, revCond, device=0, row_begin=a, row_end=b), device=0)
-        assert sl._nccl and (sl.row_begin, sl.row_end) == (0, n)
+        assert sl._nccl and (sl.row_begin, sl.row_end) == (0, n) and sl._native == (route == "library")
         ll = sl.loglik("matern", cp, tau)
         assert ll == ll1                                             # same kernel, same rows, sum of one shard
         assert sl.loglik("matern", cp, tau) == ll                    # the stream/buffer pair is reusable

@@ -605,6 +605,47 @@ def test_sgv_likelihood_fully_on_device(n, m, d, ordering):
     assert abs(ll2 - G.vecchia_likelihood_U(z, U_obj)) <= 1e-9 * abs(ll2)
 
 
+def test_totals_by_sequence_number_and_by_stream_wait_interleave():
+    """Plain evaluations hand their totals to the host through a sequence number the set kernel stores behind them (no stream
+    wait); evaluations with a posterior pass, or into a caller's device buffer, are waited for on the stream.  One plan
+    alternating between the three always returns the totals of ITS LATEST evaluation."""
+    G = _need_gpu()
+    import torch
+    rng = np.random.default_rng(77)
+    n, m = 30000, 15
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+    nn, cd = va["U_prep"]["revNNarray"], va["U_prep"]["revCond"]
+
+    def make():
+        pl = G.Plan(va["locsord"], nn, cd)
+        pl.set_data(z[va["ord_z"] - 1])
+        pl.build_posterior()
+        return pl
+    pA, pB = ([1.0, 0.05, 1.5], 0.1), ([2.5, 0.11, 0.5], 0.7)
+    F_plain, F_post = G.GPV_WANT_NUMERATOR, G.GPV_WANT_DENOM
+    want = {}
+    for tag, par in (("A", pA), ("B", pB)):
+        for fl in (F_plain, F_post):
+            pl = make()
+            pl.eval("matern", par[0], par[1], fl)
+            want[tag, fl] = pl.sums()
+    assert not np.array_equal(want["A", F_plain], want["A", F_post])
+    plan = make()
+    dev = torch.zeros(8, dtype=torch.float64, device="cuda")
+    order = [("A", F_plain), ("B", F_post), ("B", F_plain), ("A", F_post), ("A", F_plain), ("A", F_plain), ("B", F_plain)] * 3
+    for i, (tag, fl) in enumerate(order):
+        par = pA if tag == "A" else pB
+        if i % 5 == 4:                                             # a caller's device buffer: nothing reaches the host by itself
+            plan.eval("matern", par[0], par[1], fl, d_sums_out=dev.data_ptr())
+            np.testing.assert_array_equal(plan.sums(), want[tag, fl])
+            np.testing.assert_array_equal(dev.cpu().numpy(), want[tag, fl])
+        else:
+            plan.eval("matern", par[0], par[1], fl)
+            np.testing.assert_array_equal(plan.sums(), want[tag, fl])
+            np.testing.assert_array_equal(plan.sums(), want[tag, fl])          # a second read finds the same number
+
+
 @pytest.mark.parametrize("covmodel,cp", [("matern", [1.3, 0.2, 0.5]), ("matern", [1.3, 0.2, 1.5]), ("matern", [0.7, 0.2, 2.5]),
                                          ("matern", [1.1, 0.2, 1.1]), ("esqe", [0.9, 0.3, 0.4, 0.2])])
 @pytest.mark.parametrize("d", [1, 2, 3])

@@ -22,6 +22,20 @@ newest = lambda fs: sorted(fs, key=os.path.getmtime)[-1:]          # gpurun merg
 st = newest(glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True))
 if st:
     shutil.copy(st[0], os.path.join(P, name + "_kernel_stats.csv"))
+# the launches of the set kernel one by one (the bench command precedes its K timed steps with a clock warm-up, whose first
+# ~25 launches run at a rising shader clock): overall mean, mean of the last K = the timed region
+tr = newest(glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True))
+if tr:
+    rows = [r for r in csv.DictReader(open(tr[0])) if "gpv_sets_kernel" in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    us = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
+    K = json.loads(line)["steps"]
+    json.dump({"kernel": rows[0]["Kernel_Name"].split("(")[0] if rows else None, "launches": len(us),
+               "mean_us_all_launches": sum(us) / max(len(us), 1),
+               "timed_region": {"launches": K, "mean_us": sum(us[-K:]) / max(len(us[-K:]), 1), "min_us": min(us[-K:]), "max_us": max(us[-K:])},
+               "first_launches_us": [round(u, 1) for u in us[:30]],
+               "bench_kernel_ms_hipEvents_same_run": json.loads(line)["roofline"]["kernel_ms"]},
+              open(os.path.join(P, name + "_kernel_launches.json"), "w"), indent=1)
 tot = {}
 for i in (1, 2, 3, 4):
     fs = newest(glob.glob(os.path.join(src, f"pmc{i}", "**", "*counter_collection.csv"), recursive=True))

@@ -11,6 +11,6 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
          "GRBM_GUI_ACTIVE FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $OUT/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc$i -- python3 bench.py --steps 3 --warmup 1 --clock-warmup-s 0 --no-cpu-baseline --no-secondary "$@" > $OUT/pmc$i.log 2>&1
 done
 tail -c 3000 $OUT/bench.json
