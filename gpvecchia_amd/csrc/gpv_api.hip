@@ -336,7 +336,9 @@ struct gpv_plan {
     // general-nu Matern: range of pair distances of the plan (parameter independent) and the per-evaluation table
     double coord_maxabs = 0.0;                       // largest finite |coordinate| (guards the kernel's pre-scaled coordinates)
     double dist_min = 0.0, dist_max = 0.0;
-    std::vector<int64_t> dist_hist;                  // point-to-neighbour distances by binary exponent (index = exponent + 1100)
+    // distances of ALL pairs inside a sample of the conditioning sets, by quarter octave (index = floor(4 log2 d) + 4400):
+    // where the set kernel's LDS window of the general-nu table goes
+    std::vector<int64_t> dist_hist;
     double *h_mt2[2] = {nullptr, nullptr}, *d_mt2[2] = {nullptr, nullptr};   // pinned staging / device copies, used alternately
     hipEvent_t mt_ev[2] = {nullptr, nullptr};
     int mt_slot = 0, mt_pending = -1;
@@ -622,29 +624,43 @@ static int plan_create_impl(gpv_plan **out, int device, int64_t Nlocs, int dim, 
     if (locs) {
         std::mutex mu_;
         double gmin = INFINITY, gmax = 0.0;
-        pl->dist_hist.assign(2200, 0);
+        constexpr int kHist = 8800;
+        pl->dist_hist.assign(kHist, 0);
+        const int64_t stride = Nlocs > 8192 ? Nlocs / 4096 : 1;          // the pairs of ~4096 sets: ~2e6 distances
         parallel_for(Nlocs, [&](int64_t b, int64_t e) {
             double lmin = INFINITY, lmax = 0.0;
-            std::vector<int64_t> lh(2200, 0);
+            std::vector<int64_t> lh(kHist, 0);
+            std::vector<int> members((size_t)ncolNN);
+            auto dist_of = [&](int a1, int b1) {
+                double r2 = 0.0;
+                for (int t = 0; t < dim; ++t) {
+                    const double df = locs[(a1 - 1) + (int64_t)t * Nlocs] - locs[(b1 - 1) + (int64_t)t * Nlocs];
+                    r2 += df * df;
+                }
+                return std::sqrt(r2);
+            };
             for (int64_t k = b; k < e; ++k) {
                 const int self = revNN[k + (int64_t)(ncolNN - 1) * Nlocs];
                 if (is_missing(self) || self < 1 || (int64_t)self > Nlocs) continue;
+                int nm = 0;
                 for (int j = 0; j < ncolNN - 1; ++j) {
                     const int v = revNN[k + (int64_t)j * Nlocs];
                     if (is_missing(v) || v < 1 || (int64_t)v > Nlocs) continue;
-                    double r2 = 0.0;
-                    for (int t = 0; t < dim; ++t) {
-                        const double df = locs[(self - 1) + (int64_t)t * Nlocs] - locs[(v - 1) + (int64_t)t * Nlocs];
-                        r2 += df * df;
-                    }
-                    const double dd = std::sqrt(r2);
+                    members[(size_t)nm++] = v;
+                    const double dd = dist_of(self, v);
                     if (dd > lmax) lmax = dd;                    // first valid entry is the farthest, but rows need not be sorted
                     if (dd > 0.0 && dd < lmin) lmin = dd;
-                    if (dd > 0.0 && std::isfinite(dd)) {
-                        int ex = std::ilogb(dd) + 1100;
-                        lh[(size_t)(ex < 0 ? 0 : (ex > 2199 ? 2199 : ex))]++;
-                    }
                 }
+                if (k % stride != 0) continue;
+                members[(size_t)nm++] = self;
+                for (int a1 = 1; a1 < nm; ++a1)
+                    for (int b1 = 0; b1 < a1; ++b1) {
+                        const double dd = dist_of(members[(size_t)a1], members[(size_t)b1]);
+                        if (dd > 0.0 && std::isfinite(dd)) {
+                            const int ex = (int)std::floor(4.0 * std::log2(dd)) + kHist / 2;
+                            lh[(size_t)(ex < 0 ? 0 : (ex > kHist - 1 ? kHist - 1 : ex))]++;
+                        }
+                    }
             }
             std::lock_guard<std::mutex> g(mu_);
             if (lmin < gmin) gmin = lmin;
@@ -808,36 +824,45 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             } else {
                 GPV_HIP(hipEventSynchronize(pl->mt_ev[sl]));              // two evaluations ago: long done in steady state
             }
-            int full = 0;
-            matern_tab_build(cs.sB, 0.5 * pl->dist_min * cs.cA, 4.0 * pl->dist_max * cs.cA, cs.sA, pl->h_mt2[sl], &a.mt_base,
-                             &a.mt_nseg, kMaxSeg, &full);
+            int full = 0, e_lo = 0;
+            static const bool host_fit = getenv("GPV_MATERN_TABLE_HOST") != nullptr;    // cross-check of the device fit
+            const double s_lo = 0.5 * pl->dist_min * cs.cA, s_hi = 4.0 * pl->dist_max * cs.cA;
+            if (host_fit) matern_tab_build(cs.sB, s_lo, s_hi, cs.sA, pl->h_mt2[sl], &a.mt_base, &a.mt_nseg, kMaxSeg, &full);
+            else (void)matern_tab_range(s_lo, s_hi, kMaxSeg, &e_lo, &a.mt_base, &a.mt_nseg, &full);
             a.mt_full = (a.mt_nseg > 0 && full) ? 1 : 0;
-            // LDS window of the kernel (gpv_sets_kernel.hpp, mt_window_rows): the 6 octaves of s = dist/range that hold most of
-            // the plan's point-to-neighbour distances, shifted up half an octave for the neighbour-to-neighbour pairs
+            // LDS window of the kernel (gpv_sets_kernel.hpp, mt_window_rows): the octaves of s = dist/range -- as many as the
+            // instantiation has room for -- that hold most of the pair distances inside the plan's conditioning sets
             a.mt_win = 0;
-            if (a.mt_nseg > 0 && !pl->dist_hist.empty()) {
+            const int win_oct = sets_mt_window_rows(pl->P, pl->dim) / MaternTab::SPO;
+            if (a.mt_nseg > 0 && win_oct > 0 && !pl->dist_hist.empty()) {
                 const int e_lo = (a.mt_base >> MaternTab::LSPO) - 1023;   // binary exponent of the table's first segment
                 const int noct = a.mt_nseg / MaternTab::SPO;
-                const double sh = std::log2(cs.cA) + 0.5;
+                const double sh = std::log2(std::fabs(cs.cA));
+                const int kHist = (int)pl->dist_hist.size();
                 std::vector<double> H((size_t)noct, 0.0);
-                for (int ex = 0; ex < 2200; ++ex) {
+                for (int ex = 0; ex < kHist; ++ex) {
                     if (!pl->dist_hist[(size_t)ex]) continue;
-                    const int o = (int)std::floor((double)(ex - 1100) + sh) - e_lo;
+                    const int o = (int)std::floor(((double)(ex - kHist / 2) + 0.5) * 0.25 + sh) - e_lo;   // the bin's centre
                     if (o >= 0 && o < noct) H[(size_t)o] += (double)pl->dist_hist[(size_t)ex];
                 }
                 double best = -1.0;
                 int bo = 0;
-                for (int o = 0; o + 6 <= noct || o == 0; ++o) {
-                    double m6 = 0.0;
-                    for (int t = 0; t < 6 && o + t < noct; ++t) m6 += H[(size_t)(o + t)];
-                    if (m6 > best) { best = m6; bo = o; }
-                    if (o + 6 > noct) break;
+                for (int o = 0; o + win_oct <= noct || o == 0; ++o) {
+                    double mw = 0.0;
+                    for (int t = 0; t < win_oct && o + t < noct; ++t) mw += H[(size_t)(o + t)];
+                    if (mw > best) { best = mw; bo = o; }
+                    if (o + win_oct > noct) break;
                 }
                 a.mt_win = MaternTab::SPO * bo;
             }
             if (a.mt_nseg > 0) {
-                GPV_HIP(hipMemcpyAsync(pl->d_mt2[sl], pl->h_mt2[sl], sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
-                                       hipMemcpyHostToDevice, st));
+                // the fit runs on the evaluation's stream in front of the set kernel (~10 us; on the host it was 0.3 ms in
+                // series with every optimiser step); the stream orders it behind the previous evaluation's reads
+                if (host_fit)
+                    GPV_HIP(hipMemcpyAsync(pl->d_mt2[sl], pl->h_mt2[sl], sizeof(double) * (size_t)a.mt_nseg * MaternTab::ROW,
+                                           hipMemcpyHostToDevice, st));
+                else
+                    GPV_HIP(launch_matern_tab(cs.sB, e_lo, a.mt_nseg, cs.sA, pl->d_mt2[sl], st));
                 a.mt = pl->d_mt2[sl];
             }
             pl->mt_pending = sl;

@@ -29,6 +29,20 @@ int max_P()
     for (int v : kPList) m = v > m ? v : m;
     return m;
 }
+// rows of the general-nu table the instantiation (P, dim) keeps in LDS (gpv_sets_kernel.hpp, mt_window_rows); 0 = none
+int sets_mt_window_rows(int P, int dim)
+{
+    switch (P) {
+#define GPV_CASE(P_)                                                                                       \
+    case P_:                                                                                               \
+        return dim == 1 ? mt_window_rows<P_, 1, COV_MATERN_GEN>() : dim == 2 ? mt_window_rows<P_, 2, COV_MATERN_GEN>() \
+             : dim == 3 ? mt_window_rows<P_, 3, COV_MATERN_GEN>() : 0;
+        GPV_P_LIST(GPV_CASE)
+#undef GPV_CASE
+        default:
+            return 0;
+    }
+}
 hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
 {
     switch (P) {
@@ -54,6 +68,96 @@ hipError_t launch_publish_sums(const double *sums, double *host_sums, unsigned l
                                hipStream_t s)
 {
     hipLaunchKernelGGL(gpv_publish_sums_kernel, dim3(1), dim3(64), 0, s, sums, host_sums, seq_cells, seq);
+    return hipGetLastError();
+}
+
+// ---- general-nu Matern: the per-evaluation table of h(s) = scale s^nu K_nu(s) e^s, fitted on the device ----------------
+// One workgroup per segment (gpv_bessel.hpp, MaternTab), one wavefront per Chebyshev node of the segment: the 64 lanes share
+// the trapezoidal sum of K_mu and K_{mu+1} at that node (lane l takes the quadrature points l+1, l+65, ...; same step, same
+// integrand as bessel_k_scaled), the 11 node values meet in LDS, and 11 threads turn them into Chebyshev and then monomial
+// coefficients.  ~1e3 wavefronts of a few hundred instructions: ~10 us on the evaluation's own stream, where the host fit
+// (0.3 ms on four threads, serial with every optimiser step) used to sit.
+constexpr int kTabN = MaternTab::DEG + 1;
+__global__ void __launch_bounds__(kTabN * 64) gpv_matern_tab_kernel(double nu, int e_lo, double scale, double *rows)
+{
+    __shared__ double f[kTabN], ch[kTabN], tk[kTabN][kTabN];
+    const int seg = blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+    constexpr int SPO = MaternTab::SPO;
+    const int e = e_lo + seg / SPO, m = seg % SPO;
+    const double c = ldexp(1.0 + ((double)m + 0.5) / SPO, e), hw = ldexp(1.0, e - 1 - MaternTab::LSPO);
+    const double x = c + hw * cospi(((double)j + 0.5) / kTabN);
+    const int n_up = (int)(nu + 0.5);
+    const double mu = nu - (double)n_up;
+    const double h1 = 9.8696044010893586188 / (x + 44.0), h2 = 0.66 / sqrt(x);
+    const double h = h1 < h2 ? h1 : h2;
+    const double t_end = 2.0 * asinh(sqrt(372.5 / x));              // beyond it x (cosh t - 1) > 745: the weight is 0 in FP64
+    const int npts = (int)(t_end / h) + 1;
+    double s0 = 0.0, s1 = 0.0;
+    for (int q = lane + 1; q <= npts; q += 64) {
+        const double t = (double)q * h;
+        const double sh = sinh(0.5 * t);
+        const double w = exp(-2.0 * x * sh * sh);
+        const double gm = exp(mu * t), g1 = gm * exp(t);
+        s0 = __builtin_fma(w, 0.5 * (gm + 1.0 / gm), s0);
+        s1 = __builtin_fma(w, 0.5 * (g1 + 1.0 / g1), s1);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+    }
+    if (threadIdx.x == 0) {                                          // T_k(u) = sum_i tk[k][i] u^i (integers up to 2^9: exact)
+        for (int k = 0; k < kTabN; ++k)
+            for (int i = 0; i < kTabN; ++i) tk[k][i] = 0.0;
+        tk[0][0] = 1.0;
+        tk[1][1] = 1.0;
+        for (int k = 2; k < kTabN; ++k)
+            for (int i = 0; i < kTabN; ++i) tk[k][i] = (i > 0 ? 2.0 * tk[k - 1][i - 1] : 0.0) - tk[k - 2][i];
+    }
+    if (lane == 0) {
+        double k0 = h * (s0 + 0.5), k1 = h * (s1 + 0.5);            // the t = 0 point carries half weight
+        const double two_over_x = 2.0 / x;
+        for (int i = 1; i <= n_up; ++i) {
+            const double up = __builtin_fma((mu + (double)i) * two_over_x, k1, k0);
+            k0 = k1;
+            k1 = up;
+        }
+        f[j] = exp(nu * log(x) - (e < MaternTab::FOLD_EXP ? x : 0.0)) * k0;   // below s = 4 the row carries exp(-s) as well
+    }
+    __syncthreads();
+    if (threadIdx.x < kTabN) {
+        const int k = threadIdx.x;
+        double a = 0.0;
+        for (int i = 0; i < kTabN; ++i) a = __builtin_fma(f[i], cospi((double)k * ((double)i + 0.5) / kTabN), a);
+        ch[k] = a * (k == 0 ? 1.0 : 2.0) / kTabN;
+    }
+    __syncthreads();
+    __shared__ double mono[kTabN];
+    if (threadIdx.x < kTabN) {
+        const int i = threadIdx.x;
+        double a = 0.0;
+        for (int k = kTabN - 1; k >= i; --k) a = __builtin_fma(ch[k], tk[k][i], a);       // smallest terms first
+        mono[i] = a * scale;
+    }
+    __syncthreads();
+    // the row format of gpv_bessel.hpp: a_0 .. a_6 doubles, a_7 .. a_10 floats relative to 2^E, E = exponent of a_0
+    double *row = rows + (size_t)seg * MaternTab::ROW;
+    if (threadIdx.x < MaternTab::NDBL) row[threadIdx.x] = mono[threadIdx.x];
+    if (threadIdx.x < 2) {
+        const double a0 = mono[0];
+        const int E = (a0 != 0.0 && isfinite(a0)) ? ilogb(a0) : 0;
+        float t[2];
+        for (int k = 0; k < 2; ++k) {
+            const double v = ldexp(mono[MaternTab::NDBL + 2 * threadIdx.x + k], -E);
+            t[k] = (fabs(v) < 3.0e38) ? (float)v : (v > 0 ? 3.0e38f : -3.0e38f);
+            if (v != v) t[k] = (float)v;
+        }
+        row[MaternTab::NDBL + threadIdx.x] = __hiloint2double(__float_as_int(t[1]), __float_as_int(t[0]));
+    }
+}
+hipError_t launch_matern_tab(double nu, int e_lo, int nseg, double scale, double *rows, hipStream_t s)
+{
+    if (nseg <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gpv_matern_tab_kernel, dim3(nseg), dim3(kTabN * 64), 0, s, nu, e_lo, scale, rows);
     return hipGetLastError();
 }
 

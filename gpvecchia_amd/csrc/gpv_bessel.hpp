@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -86,29 +87,59 @@ __host__ __device__ inline double matern_general(const double s, const double no
 // (rows are gathered by every lane's own distance), so the row is as short as the accuracy allows: round 2 began with
 // four segments per octave at degree 12 in the Chebyshev basis (128-byte rows, Clenshaw).  The device multiplies by
 // exp(-s); distances outside the tabulated range are evaluated by the quadrature above.
+// Round 3: the rows of the segments BELOW s = 4 (binary exponent < FOLD_EXP) hold the covariance itself, scale s^nu K_nu(s),
+// with exp(-s) folded in: there the half-width is at most 1/8, exp(-s) is as well approximated as h (its Taylor terms fall
+// like (1/8)^k / k!, 3e-18 at k = 11), and a wave whose 64 arguments all lie below 4 -- every pair of a plan whose range
+// is not far below its neighbour distances -- skips the 18 instructions of exp(-s) per pair.
+// Row format (round 3: 72 bytes instead of 96, so that the LDS window of the set kernel spans 8 octaves instead of 6 in the same
+// space; a lane whose segment misses the window waits for a row from global memory, and 23 % of the pair rounds had such a
+// lane with 6 octaves, 2 % with 8): a_0 .. a_6 as doubles, a_7 .. a_10 as FLOATS relative to 2^E, E = the binary exponent of
+// a_0 (two per double slot, low word first).  a_k falls like 17^-k, so the tail a_7 u^7 + .. is below 2.4e-9 |a_0| and its
+// float rounding (6e-8) below 1.5e-16; it is evaluated in FP32 as well and joins the FP64 Horner chain through one
+// conversion and one multiplication by 2^E (the exponent bits of a_0).
 struct MaternTab {
-    static constexpr int DEG = 10, ROW = 12, LSPO = 3, SPO = 1 << LSPO;     // degree, doubles per row, segments per octave
+    static constexpr int DEG = 10, NDBL = 7, ROW = 9, LSPO = 3, SPO = 1 << LSPO;   // degree, double coefficients, doubles per row, segments per octave
+    static constexpr int FOLD_EXP = 2;                                      // segments with binary exponent < 2 carry exp(-s)
 };
+// the host side of the format: monomial coefficients a[0..DEG] (already scaled) -> one row
+inline void matern_tab_pack_row(const double *a, double *row)
+{
+    for (int j = 0; j < MaternTab::NDBL; ++j) row[j] = a[j];
+    int E = 0;
+    if (a[0] != 0.0 && std::isfinite(a[0])) (void)std::frexp(a[0], &E), E -= 1;       // a_0 = m 2^E, 1 <= |m| < 2
+    float t[4];
+    for (int k = 0; k < 4; ++k) {
+        const double v = std::ldexp(a[MaternTab::NDBL + k], -E);
+        t[k] = (std::fabs(v) < 3.0e38) ? (float)v : (v > 0 ? 3.0e38f : -3.0e38f);
+        if (v != v) t[k] = (float)v;
+    }
+    std::memcpy(row + MaternTab::NDBL, t, sizeof(t));
+}
+#define GPV_MT_FOLD_BELOW 4.0                                               // = 2^FOLD_EXP
 __device__ __forceinline__ int matern_tab_segment(const double s, const int base)
 {
     return (int)(__double_as_longlong(s) >> (52 - MaternTab::LSPO)) - base;
 }
-__device__ __forceinline__ double matern_tab_poly(const double2 q0, const double2 q1, const double2 q2, const double2 q3,
-                                                  const double2 q4, const double2 q5, const double s)
+// r[0..6] = a_0 .. a_6, r[7] = {t_7, t_8}, r[8] = {t_9, t_10} (floats)
+__device__ __forceinline__ double matern_tab_poly(const double (&r)[MaternTab::ROW], const double s)
 {
-    const unsigned long long gb = (((unsigned long long)__double_as_longlong(s) << MaternTab::LSPO) & 0x000FFFFFFFFFFFFFull) |
-                                  0x3FF0000000000000ull;
-    const double u = __builtin_fma(__longlong_as_double((long long)gb), 2.0, -3.0);
-    double p = __builtin_fma(q5.x, u, q4.y);
-    p = __builtin_fma(p, u, q4.x);
-    p = __builtin_fma(p, u, q3.y);
-    p = __builtin_fma(p, u, q3.x);
-    p = __builtin_fma(p, u, q2.y);
-    p = __builtin_fma(p, u, q2.x);
-    p = __builtin_fma(p, u, q1.y);
-    p = __builtin_fma(p, u, q1.x);
-    p = __builtin_fma(p, u, q0.y);
-    return __builtin_fma(p, u, q0.x);
+    // g = the mantissa of s shifted left by LSPO bits under the exponent of 1.0, u = 2 g - 3; as two 32-bit halves: a funnel
+    // shift, a shift and an and-or (the 64-bit form cost a quarter-rate 64-bit shift and two needless ands)
+    const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
+    const unsigned ghi = (__builtin_amdgcn_alignbit(hi, lo, 32 - MaternTab::LSPO) & 0x000FFFFFu) | 0x3FF00000u;
+    const double u = __builtin_fma(__hiloint2double((int)ghi, (int)(lo << MaternTab::LSPO)), 2.0, -3.0);
+    const float uf = (float)u;
+    float t = __builtin_fmaf(__int_as_float(__double2hiint(r[8])), uf, __int_as_float(__double2loint(r[8])));
+    t = __builtin_fmaf(t, uf, __int_as_float(__double2hiint(r[7])));
+    t = __builtin_fmaf(t, uf, __int_as_float(__double2loint(r[7])));
+    const double pw = __hiloint2double(__double2hiint(r[0]) & 0x7FF00000, 0);      // 2^E
+    double p = __builtin_fma((double)t * pw, u, r[6]);
+    p = __builtin_fma(p, u, r[5]);
+    p = __builtin_fma(p, u, r[4]);
+    p = __builtin_fma(p, u, r[3]);
+    p = __builtin_fma(p, u, r[2]);
+    p = __builtin_fma(p, u, r[1]);
+    return __builtin_fma(p, u, r[0]);
 }
 
 // The same quadrature for MANY arguments at one order (the table fit below evaluates K_nu ~1.5e3 times per likelihood
@@ -165,21 +196,35 @@ struct BesselQuadNodes {
     }
 };
 
-// *full (may be nullptr): 1 when [smin, smax] lies inside the tabulated range (nothing was cut at either end)
-inline void matern_tab_build(double nu, double smin, double smax, double scale, double *rows /* nseg x ROW */, int *base_idx,
-                             int *nseg, int max_seg, int *full = nullptr)
+// Which segments a table for arguments in [smin, smax] holds: binary exponent of the first one, index base for
+// matern_tab_segment, their number.  *full (may be nullptr): 1 when [smin, smax] lies inside the tabulated range (nothing was
+// cut at either end).  Returns false when there is nothing to tabulate.
+inline bool matern_tab_range(double smin, double smax, int max_seg, int *e_lo_out, int *base_idx, int *nseg, int *full = nullptr)
 {
     if (full) *full = 0;
-    constexpr int N = MaternTab::DEG + 1, SPO = MaternTab::SPO;
+    constexpr int SPO = MaternTab::SPO;
     int e_lo = (int)std::floor(std::log2(smin)), e_hi = (int)std::floor(std::log2(smax));
     bool cut = false;
     if (e_lo < -200) { e_lo = -200; cut = true; }
     if (e_hi > 8) { e_hi = 8; cut = true; }                   // s < 512: K_nu(s) e^s stays in range; beyond, the value is ~0 anyway
-    if (e_hi < e_lo) { *nseg = 0; *base_idx = 0; return; }
+    if (e_hi < e_lo) { *nseg = 0; *base_idx = 0; *e_lo_out = 0; return false; }
     if ((e_hi - e_lo + 1) * SPO > max_seg) { e_lo = e_hi + 1 - max_seg / SPO; cut = true; }
     if (full) *full = cut ? 0 : 1;
+    *e_lo_out = e_lo;
     *base_idx = (e_lo + 1023) << MaternTab::LSPO;
     *nseg = (e_hi - e_lo + 1) * SPO;
+    return true;
+}
+
+// The fit on the host (the evaluation path fits on the device: gpv_matern_tab_kernel, gpv_aux_kernels.hip; this one is kept
+// as its cross-check, GPV_MATERN_TABLE_HOST=1)
+inline void matern_tab_build(double nu, double smin, double smax, double scale, double *rows /* nseg x ROW */, int *base_idx,
+                             int *nseg, int max_seg, int *full = nullptr)
+{
+    constexpr int N = MaternTab::DEG + 1, SPO = MaternTab::SPO;
+    int e_lo = 0;
+    if (!matern_tab_range(smin, smax, max_seg, &e_lo, base_idx, nseg, full)) return;
+    const int e_hi = e_lo + *nseg / SPO - 1;
     double cs[N][N];
     for (int k = 0; k < N; ++k)
         for (int j = 0; j < N; ++j) cs[k][j] = std::cos(3.14159265358979323846 * k * (j + 0.5) / N);
@@ -212,7 +257,7 @@ inline void matern_tab_build(double nu, double smin, double smax, double scale, 
         double f[N];
         for (int j = 0; j < N; ++j) {
             const double s = c + hw * cs[1][j];
-            f[j] = std::exp(nu * std::log(s)) * kscaled(s);
+            f[j] = std::exp(nu * std::log(s) - (e < MaternTab::FOLD_EXP ? s : 0.0)) * kscaled(s);
         }
         long double ch[N];
         for (int k = 0; k < N; ++k) {
@@ -220,13 +265,13 @@ inline void matern_tab_build(double nu, double smin, double smax, double scale, 
             for (int j = 0; j < N; ++j) a += (long double)f[j] * (long double)cs[k][j];
             ch[k] = a * (k == 0 ? 1.0L : 2.0L) / N;
         }
-        double *row = rows + (size_t)seg * MaternTab::ROW;
+        double mono[N];
         for (int j = 0; j < N; ++j) {
             long double a = 0.0L;
             for (int k = N - 1; k >= j; --k) a += ch[k] * (long double)tk[k][j];     // smallest terms first
-            row[j] = (double)(a * (long double)scale);
+            mono[j] = (double)(a * (long double)scale);
         }
-        for (int j = N; j < MaternTab::ROW; ++j) row[j] = 0.0;
+        matern_tab_pack_row(mono, rows + (size_t)seg * MaternTab::ROW);
     }
     };
     unsigned hw = std::thread::hardware_concurrency();

@@ -57,11 +57,16 @@ struct SetArgs {
 hipError_t launch_sets(int P, const SetArgs &a, int cus, int *grid_out, hipStream_t stream);
 // smallest compiled P >= p, or 0
 int pick_P(int p);
+// rows of the general-nu Matern table the instantiation (P, dim) keeps in LDS (0: none)
+int sets_mt_window_rows(int P, int dim);
 int max_P();
 
 // the 8 totals in `sums` (device) -> host memory with the sequence-number hand-off of SetArgs::seq_cells (one 64-thread launch)
 hipError_t launch_publish_sums(const double *sums, double *host_sums, unsigned long long *seq_cells, unsigned long long seq,
                                hipStream_t s);
+
+// general nu: fit the nseg rows of the Matern table whose first segment has binary exponent e_lo (gpv_bessel.hpp) on the device
+hipError_t launch_matern_tab(double nu, int e_lo, int nseg, double scale, double *rows, hipStream_t s);
 
 // small helper kernels (gpv_aux_kernels.hip)
 hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);

@@ -262,7 +262,7 @@ constexpr int blocks_per_cu()
 // octaves chosen by the host where the plan's pair distances concentrate).  From global memory the 8 x 16-byte row
 // gathers per pair make the kernel texture-address bound (5.2 ms against 1.55 ms for a closed form at n = 1e6, m = 30);
 // the window takes exactly the LDS the instantiation leaves unused at its occupancy, so it never costs a workgroup.
-constexpr int kMtRowLds = MaternTab::ROW;           // doubles per LDS row (96 bytes)
+constexpr int kMtRowLds = MaternTab::ROW;           // doubles per LDS row (72 bytes)
 template <int P, int D, int COV>
 constexpr int mt_window_rows()
 {
@@ -270,7 +270,7 @@ constexpr int mt_window_rows()
     const int w = wpb<P, D, COV>();
     const long left = 163840 / blocks_per_cu<P, D, COV>() - (long)sizeof(SetsLds<P, D, COV>) * w - 64;
     long rows = left / (kMtRowLds * 8);
-    rows = rows > 8 * MaternTab::SPO ? 8 * MaternTab::SPO : rows;
+    rows = rows > 10 * MaternTab::SPO ? 10 * MaternTab::SPO : rows;
     rows &= ~(long)(MaternTab::SPO - 1);            // whole octaves
     return rows < 2 * MaternTab::SPO ? 0 : (int)rows;
 }
@@ -507,9 +507,12 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
 {
     const int seg = matern_tab_segment(s, mt_base);
     if ((unsigned)seg < (unsigned)mt_nseg) {
-        const double2 *row = reinterpret_cast<const double2 *>(mt + (size_t)seg * MaternTab::ROW);
-        const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
-        return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg(s);               // (normcon is in the table)
+        const double *row = mt + (size_t)seg * MaternTab::ROW;
+        double r[MaternTab::ROW];
+#pragma unroll
+        for (int c = 0; c < MaternTab::ROW; ++c) r[c] = row[c];
+        const double pv = matern_tab_poly(r, s);                                     // (normcon is in the table)
+        return s < GPV_MT_FOLD_BELOW ? pv : pv * exp_neg(s);                         // (below 4: exp(-s) as well)
     }
     return matern_general(s, normcon, nu);
 }
@@ -521,26 +524,48 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
 // in a loop of its own (cov_rounds_fast): inlined at the 60 places of the rounds, that fallback cost the hot path hundreds
 // of spilled registers.  A wave whose 64 segments all sit in the LDS window (the common case) is inside the table by
 // construction and takes no range test.  `live` = the pair's value is used (a zero distance is replaced by sigma^2).
+// Two stages, so that the rounds can fetch the rows of round s + 1 before they evaluate round s (cov_rounds_fast):
+//   matern_table_fetch: the row of the lane's segment into r[] -- from the LDS window when the segment sits in it, else from
+//     the table in global memory (a few lanes of a wave at most: with every lane sent to global memory as soon as one of the
+//     64 fell outside, 44 % of the rounds gathered 64 x 96 bytes through the texture path; profiles/r03_nu11_pmc_summary.json,
+//     22.6 M VMEM reads).  Every lane reads LDS (an outside lane row 0), the global row then overwrites in place.
+//   matern_table_value: the polynomial, and exp(-s) where the row does not carry it.
 template <int MTW>
-__device__ __forceinline__ double matern_table_only(const SetArgs &A, const double *mt_lds, double s, bool live, const ExpScaled &E,
-                                                    unsigned long long &need, const int bit)
+__device__ __forceinline__ void matern_table_fetch(const SetArgs &A, const double *mt_lds, double s, bool live, double (&r)[MaternTab::ROW],
+                                                   unsigned long long &need, const int bit)
 {
-    const int seg0 = matern_tab_segment(s, A.mt_base);
+    const int rel = (__double2hiint(s) >> (20 - MaternTab::LSPO)) - (A.mt_base + A.mt_win);     // segment relative to the window
+    const bool in = MTW > 0 && (unsigned)rel < (unsigned)MTW && A.mt_nseg > 0;
+#pragma unroll
+    for (int c = 0; c < MaternTab::ROW; ++c) r[c] = 0.0;
     if constexpr (MTW > 0) {
-        const int rel = seg0 - A.mt_win;
-        const bool in = (unsigned)rel < (unsigned)MTW && A.mt_nseg > 0;
-        if (__builtin_amdgcn_ballot_w64(!in) == 0) {                // wave uniform: every lane's segment sits in the LDS window
-            const double2 *row = reinterpret_cast<const double2 *>(mt_lds + rel * kMtRowLds);
-            const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
-            return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);   // E: scale 1 (normcon is in the table)
+        // byte address = window + 72 rel as two shift-adds (hipcc turns any form of the product, __umul24 included, into the
+        // quarter-rate v_mul_lo_u32; the empty asm keeps it from putting the two halves back together)
+        static_assert(kMtRowLds * 8 == 72, "row stride");
+        const unsigned relc = in ? (unsigned)rel : 0u;
+        unsigned a64 = lds_addr(mt_lds) + (relc << 6);
+        asm volatile("" : "+v"(a64));
+        const lds_cdouble *rowl = lds_ptr(a64 + (relc << 3));
+#pragma unroll
+        for (int c = 0; c < MaternTab::ROW; ++c) r[c] = rowl[c];
+    }
+    if (!in) {
+        const int seg0 = rel + A.mt_win;
+        need |= (unsigned long long)(live && !((unsigned)seg0 < (unsigned)A.mt_nseg)) << bit;
+        if (A.mt_nseg > 0) {                                         // (no table: kernel argument, uniform; every live pair is redone)
+            const int seg = seg0 < 0 ? 0 : (seg0 >= A.mt_nseg ? A.mt_nseg - 1 : seg0);
+            const double *row = A.mt + (size_t)seg * MaternTab::ROW;
+#pragma unroll
+            for (int c = 0; c < MaternTab::ROW; ++c) r[c] = row[c];
         }
     }
-    need |= (unsigned long long)(live && !((unsigned)seg0 < (unsigned)A.mt_nseg)) << bit;   // (only this path pays for the flag)
-    if (A.mt_nseg <= 0) return 0.0;                                 // no table (kernel argument: uniform)
-    const int seg = seg0 < 0 ? 0 : (seg0 >= A.mt_nseg ? A.mt_nseg - 1 : seg0);
-    const double2 *row = reinterpret_cast<const double2 *>(A.mt + (size_t)seg * MaternTab::ROW);
-    const double2 q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3], q4 = row[4], q5 = row[5];
-    return matern_tab_poly(q0, q1, q2, q3, q4, q5, s) * exp_neg_scaled(s, E);
+}
+__device__ __forceinline__ double matern_table_value(const double (&r)[MaternTab::ROW], double s, const ExpScaled &E)
+{
+    const double pv = matern_tab_poly(r, s);
+    // below s = 4 the row is the covariance (exp(-s) folded in, gpv_bessel.hpp); a wave with an argument beyond pays for exp
+    if (__builtin_amdgcn_ballot_w64(s >= GPV_MT_FOLD_BELOW) == 0) return pv;
+    return s >= GPV_MT_FOLD_BELOW ? pv * exp_neg_scaled(s, E) : pv;   // E: scale 1 (normcon is in the table)
 }
 
 // General nu, the pairs the table did not cover (bit s - 1 of `need`: the pair of row rq and its partner of round s), exactly:
@@ -591,6 +616,21 @@ __device__ __forceinline__ double cov_from_r2(double r2, double sig0, double sA,
     return (r2 == 0.0) ? sig0 : v;
 }
 
+// general nu, first stage of a pair: s = dist / range from the squared distance and the table row of its segment; returns
+// `live` (a zero distance is replaced by sigma^2, src/Matern.cpp:76)
+template <int MTW, bool SCALED, bool R2MIN>
+__device__ __forceinline__ bool gen_fetch(double r2, double cA, const SetArgs &A, const double *mt_lds, double &sg,
+                                          double (&r)[MaternTab::ROW], unsigned long long &need, const int bit, const bool pair_used)
+{
+    constexpr double kTiny = 2.2250738585072014e-308;
+    const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
+    const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
+    // (s clamped like t of the closed forms; s^nu K_nu(s) is 0 in FP64 from s ~ 800 for every nu <= 60)
+    sg = __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4);
+    matern_table_fetch<MTW>(A, mt_lds, sg, live && pair_used, r, need, bit);
+    return live;
+}
+
 // the same for the closed-form families without the dist == 0 select (5 VALU ops per pair): the squared distance
 // is clamped at the smallest normal number instead, where every closed form returns sigma^2 exactly
 // (t = c*1.5e-154 vanishes against 1 for any range above 1e-150; NaN coordinates are handled by `poison`)
@@ -603,10 +643,9 @@ __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, 
 {
     constexpr double kTiny = 2.2250738585072014e-308;
     if constexpr (COV == COV_MATERN_GEN) {
-        const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
-        const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
-        // (s clamped for the same reason as t below; s^nu K_nu(s) is 0 in FP64 from s ~ 800 for every nu <= 60)
-        const double v = matern_table_only<MTW>(A, mt_lds, __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4), live && pair_used, E, need, bit);
+        double sg, r[MaternTab::ROW];
+        const bool live = gen_fetch<MTW, SCALED, R2MIN>(r2, cA, A, mt_lds, sg, r, need, bit, pair_used);
+        const double v = matern_table_value(r, sg, E);
         return live ? v : sig0;                                      // src/Matern.cpp:76
     }
     if constexpr (!R2MIN) r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
@@ -641,11 +680,10 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     __shared__ __attribute__((aligned(16))) double mt_lds[MTW > 0 ? MTW * kMtRowLds : 2];
     if constexpr (MTW > 0) {
         if (A.mt_nseg > 0) {                             // rows [mt_win, mt_win + MTW) of this launch's table (clamped at its end)
-            constexpr int RC = MaternTab::ROW / 2;           // 16-byte pieces per row
-            for (int t = threadIdx.x; t < MTW * RC; t += W * 64) {
-                const int r = t / RC, c = t - r * RC;
+            for (int t = threadIdx.x; t < MTW * kMtRowLds; t += W * 64) {
+                const int r = t / kMtRowLds, c = t - r * kMtRowLds;
                 const int src = (A.mt_win + r < A.mt_nseg) ? A.mt_win + r : A.mt_nseg - 1;
-                reinterpret_cast<double2 *>(mt_lds + r * kMtRowLds)[c] = reinterpret_cast<const double2 *>(A.mt + (size_t)src * MaternTab::ROW)[c];
+                mt_lds[t] = A.mt[(size_t)src * MaternTab::ROW + c];
             }
             __syncthreads();
         }
@@ -912,6 +950,60 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             double xn[RPL][DD];
 #pragma unroll
             for (int q = 0; q < RPL; ++q) fetch(q, 1, xn[q]);
+            if constexpr (COV == COV_MATERN_GEN) {
+                // General nu, software pipelined by one round: the table rows of round s + 1 (distance -> segment -> LDS reads)
+                // are requested BEFORE the polynomials of round s run, so that the LDS latency of a row sits behind a round of
+                // arithmetic instead of in front of its own Horner chain (VALU busy 64 % against the closed forms' 85 % with the
+                // reads and their use back to back; the matrix rows are not in registers yet, the 2 x 9 extra doubles are free).
+                auto pair_used = [&](int q, int s) {
+                    if constexpr (!MASKED) return true;
+                    const int j = (rq[q] < P - s) ? rq[q] + s : rq[q] + s - P;
+                    bool jvalid = false;
+#pragma unroll
+                    for (int q2 = 0; q2 < RPL; ++q2) {
+                        const int jl = j - q2 * LPS;
+                        if (jl >= 0 && jl < LPS) jvalid = (vmask[q2] >> (sub * LPS + jl)) & 1ull;
+                    }
+                    return vq[q] && jvalid;
+                };
+                double sgn[RPL], rn[RPL][MaternTab::ROW];
+                bool liven[RPL], usedn[RPL];
+                auto stage_a = [&](int s) {                          // consumes xn (round s), requests round s + 1's coordinates
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        double r2 = R2MIN ? 2.2250738585072014e-308 : 0.0;
+#pragma unroll
+                        for (int t = 0; t < D; ++t) {
+                            const double df = xq[q][t] - xn[q][t];
+                            r2 = __builtin_fma(df, df, r2);
+                        }
+                        if (s < H) fetch(q, s + 1, xn[q]);
+                        usedn[q] = pair_used(q, s);
+                        liven[q] = gen_fetch<MTW, PRESCALE, R2MIN>(r2, cA, A, mt_lds, sgn[q], rn[q], need[q], s - 1, usedn[q]);
+                    }
+                };
+                stage_a(1);
+#pragma unroll
+                for (int s = 1; s <= H; ++s) {
+                    double sgc[RPL], rc[RPL][MaternTab::ROW];
+                    bool livec[RPL], usedc[RPL];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        sgc[q] = sgn[q]; livec[q] = liven[q]; usedc[q] = usedn[q];
+#pragma unroll
+                        for (int c = 0; c < MaternTab::ROW; ++c) rc[q][c] = rn[q][c];
+                    }
+                    if (s < H) stage_a(s + 1);
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        double v = matern_table_value(rc[q], sgc[q], expS);
+                        v = livec[q] ? v : sig0;                     // src/Matern.cpp:76 (a select, not a branch round the polynomial)
+                        if constexpr (MASKED) v = usedc[q] ? v : 0.0;
+                        *lds_wptr(((rq[q] < P - s) ? trA[q] : trB[q]) + 8 * s) = v;
+                        trA[q] += rq8[q] + 8 * s;                    // to round s + 1
+                    }
+                }
+            } else
 #pragma unroll
             for (int s = 1; s <= H; ++s) {
                 double xc[RPL][DD];

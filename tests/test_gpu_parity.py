@@ -571,6 +571,47 @@ def test_general_nu_through_the_hot_path(nu, cond):
     assert abs(G.vecchia_likelihood(z, pva, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)
 
 
+_TABLE_ROUTES = r"""
+import sys, json
+sys.path.insert(0, {root!r})
+import numpy as np
+import gpvecchia_amd as G
+from gpvecchia_amd import specify as S
+rng = np.random.default_rng(5)
+n, m = 4000, 20
+locs = rng.random((n, 2)); z = rng.standard_normal(n)
+NN = S.find_ordered_nn_gpu(locs, m)
+revNN = NN[:, ::-1].copy()
+revCond = np.where(revNN != 0, 0, -1).astype(np.int8); revCond[:, -1] = 1
+plan = G.Plan(locs, revNN, revCond); plan.set_data(z)
+out = {{}}
+for nu in (0.3, 1.1, 7.7, 24.0):
+    plan.eval("matern", [1.3, 0.09, nu], 0.05, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
+    L = plan.Lentries()
+    out[str(nu)] = [G.loglik_z_from_sums(plan.sums(), n), float(np.abs(L).sum()), float(L[n // 2, 3])]
+print("ROUTE " + json.dumps(out))
+"""
+
+
+def test_general_nu_table_fitted_on_the_device_equals_host_fit_and_quadrature():
+    """The per-evaluation Matern table is fitted by a kernel on the evaluation's stream.  Same numbers as the host fit it
+    replaced (GPV_MATERN_TABLE_HOST=1) and as no table at all (GPV_NO_MATERN_TABLE=1: every pair by the quadrature)."""
+    _need_gpu()
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for tag, env in (("device", {}), ("host", {"GPV_MATERN_TABLE_HOST": "1"}), ("none", {"GPV_NO_MATERN_TABLE": "1"})):
+        r = subprocess.run([sys.executable, "-c", _TABLE_ROUTES.format(root=root)], capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = json.loads([l for l in r.stdout.splitlines() if l.startswith("ROUTE ")][0][6:])
+    for nu, dev in res["device"].items():
+        for other in ("host", "none"):
+            # log-likelihood and sum |Lentries| to 2e-13; ONE small entry of a row (conditioning of its block) to 1e-11
+            for (a, b), tol in zip(zip(dev, res[other][nu]), (2e-13, 2e-13, 1e-11)):
+                assert abs(a - b) <= tol * abs(b), (nu, other, a, b)
+
+
 @pytest.mark.parametrize("n,m,d,ordering", [(400, 8, 2, "maxmin"), (1500, 20, 2, "none"), (900, 30, 2, "maxmin"),
                                              (700, 12, 3, "none"), (300, 5, 1, "coord"),
                                              (600, 45, 2, "maxmin"), (500, 63, 2, "none")])   # rows longer than 32
