@@ -1285,6 +1285,9 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
             int lpc = mean <= t16 ? 16 : (mean <= t32 ? 32 : 64);
             if (force) lpc = atoi(force);
             pl->lev_lpc[(size_t)l] = (lpc == 16 || lpc == 32) ? lpc : 64;
+            static const bool dbg = getenv("GPV_POST_DEBUG") != nullptr;       // developer: the schedule's shape, level by level
+            if (dbg) std::fprintf(stderr, "[gpv post] level %d: %d columns, mean row list %.1f, lanes/column %d\n", (int)l,
+                                  (int)(e0 - b0), mean, pl->lev_lpc[(size_t)l]);
         }
     }
     std::vector<int4> colrec(2 * (size_t)n), rowrec(nnz);
