@@ -434,6 +434,12 @@ def main():
                 host = plan.sums()
             return G.loglik_from_sums(host, n) if denom else G.loglik_z_from_sums(host, n)
         ll = None
+        # like timeit: no cyclic-GC pass inside the timed region (with torch imported a full collection walks millions of
+        # objects: one 55 ms pause was seen in a 70 ms region of 0.18 ms steps; tools/comm_diag.py).  Collected HERE, before the
+        # clock warm-up: a collection between the warm-up and the timed steps idles the GPU for ~40 ms and the clock is down again
+        import gc
+        gc.collect()
+        gc.disable()
         # clock warm-up (untimed, before the W warm-up steps): the GPU's power management drops the shader clock within
         # milliseconds of idling and takes ~35 ms of continuous work to bring it back (tools/clock_ramp.py,
         # profiles/r03_clock_ramp.txt: 1.46 -> 1.26 ms per launch over the first 25 launches at this workload); a timed region of 20
@@ -452,11 +458,6 @@ def main():
         for _ in range(warmup):
             ll = step()
         kms = []
-        # like timeit: no cyclic-GC pass inside the timed region (with torch imported a full collection walks millions of
-        # objects: one 55 ms pause was seen in a 70 ms region of 0.18 ms steps; tools/comm_diag.py)
-        import gc
-        gc.collect()
-        gc.disable()
         fence()
         t0 = time.perf_counter()
         trace = [] if os.environ.get("GPV_BENCH_TRACE") else None
