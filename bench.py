@@ -373,7 +373,14 @@ def main():
     # GPV_TORCH_ALLREDUCE=1: the round-2 route (dist.all_reduce on the plan's device buffer), kept for A/B
     comm = None
     if use_dist and backend == "nccl" and os.environ.get("GPV_TORCH_ALLREDUCE", "0") != "1" and args.mode != "S":
-        comm = G.Comm.from_torch(local_rank)
+        try:
+            comm = G.Comm.from_torch(local_rank)
+        except Exception as e:                                    # e.g. no RCCL to bind: say so, then agree on the route below
+            print(f"[bench] rank {rank}: library communicator unavailable ({e!r}); dist.all_reduce instead", file=sys.stderr)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                 # every rank takes the same route
+        if int(ok.item()) == 0:
+            comm = None
 
     ci, n, m, d, nu, rng_ = CONFIGS[args.config]
     custom = any(v is not None for v in (args.n, args.m, args.d, args.nu))
@@ -574,7 +581,10 @@ def main():
                                    + (f"; rows sharded over {world} GPU(s))" if args.emulate_world == 1 else
                                       f"; THIS RANK'S SHARD of an emulated {args.emulate_world}-rank job only)"),
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
-                       "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2)},
+                       "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2),
+                       "collective": ("none (1 rank, no launcher)" if not use_dist else
+                                      "library-owned RCCL communicator (gpv_comm), all-reduce enqueued by gpv_plan_eval" if comm is not None
+                                      else f"torch.distributed all_reduce ({backend})")},
             "roofline": roofline(k_ms, rows_rank, args.mode, traffic),
         }
         if check is not None:

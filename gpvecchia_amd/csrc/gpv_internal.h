@@ -21,13 +21,17 @@ struct SetArgs {
     const double *rec;       // dim <= 3: [Nlocs][4] packed records {c0, c1, c2, data}: ONE 32-byte gather per neighbour
     const double *locs;      // dim  > 3: [Nlocs][locs_ld] row-major coordinates (device)
     const int32_t *nn;       // [rows][P] 0-based neighbour index, -1 = missing; valid entries are the LAST n0
-    const uint8_t *cond;     // [rows][P] 1 = condition on latent y, 0 = on observed z
+    const uint8_t *cond;     // [rows][P] bit 0: 1 = condition on latent y, 0 = on observed z; bits 1..7: 1 + the entry's position in
+                             //          its column block of the posterior structure (0: none), written by gpv_plan_build_posterior
     const int32_t *rowid;    // [rows] output row of each stored set (sets are stored in Morton order of their own location)
     const double *nuggets;   // [Nlocs] per-location nuggets, or nullptr when the nugget is the constant nug_scalar
     const double *z;         // dim > 3 only: [Nlocs] ordered data or nullptr (dim <= 3: inside rec)
     const double *covvals;   // COV_DENSE: [Nlocs][Nlocs] symmetric covariance (U_NZentries_mat) or nullptr
     double *Lentries;        // [rows][P] row-major, left-aligned, or nullptr
     double *aout;            // [rows] a_k = sum_j M_j z_j over observed-conditioned neighbours (R/vecchia_likelihood.R:74) or nullptr
+    double2 *Cout;           // posterior pass: the compact (B, R) blocks; the kernel deposits the latent entries of every row (and a_k)
+    const int32_t *cboff;    //   straight into the row's block at Cout[cboff[row]] (no Lentries round trip, no compaction launch), or nullptr
+    int Cboth;               //   1: (B, B) instead of (B, 0) (cond.yz = 'zy': R := B)
     double *block_sums;      // [grid][kNSums] per-workgroup partial sums
     double *sums;            // [kNSums] their fixed-order total, written by the workgroup that finishes last (gpv_reduce_tail.hpp)
     double *sums_copy;       // second destination of the totals (the caller's all-reduce buffer) or nullptr

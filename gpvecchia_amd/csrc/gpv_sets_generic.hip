@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(kGenericThreads) gpv_sets_generic_kernel(const
                 const int v = A.nn[k * P + j];
                 if (v >= 0) {
                     loc[n0] = v;
-                    cf[n0] = A.cond[k * P + j];
+                    cf[n0] = A.cond[k * P + j] & 1;              // (bits 1..7: block position, used by the unrolled kernels only)
                     ++n0;
                 }
             }

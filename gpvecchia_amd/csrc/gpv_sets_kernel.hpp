@@ -739,7 +739,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             const int vi = A.nn[at];
             const int vc = A.cond[at];
             pidx[q] = ld ? vi : -1;
-            pcnd[q] = ld ? vc : 1;
+            pcnd[q] = ld ? vc : 1;                         // (raw byte: flag in bit 0, block position above it)
         }
     };
     load_ic(task_lo + (int64_t)jb * W + wv);
@@ -772,7 +772,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         asm volatile("" : "+v"(i));
 
         // ---- gather: indices, cond flags, coordinates, nugget, data -------------------
-        int row[RPL], idx[RPL], cnd[RPL], wslot[RPL];
+        int row[RPL], idx[RPL], cnd[RPL], cpos[RPL], wslot[RPL];
         bool valid[RPL], poison[RPL];
         double xi[RPL][(D == 0) ? 1 : D];
         double nugraw[RPL], zi[RPL];
@@ -782,7 +782,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             row[q] = i + q * LPS;
             wslot[q] = lane_on ? row[q] : COLS - 1;          // idle lanes write to the dump slot: no branches in the sweep
             idx[q] = pidx[q];
-            cnd[q] = pcnd[q];
+            cnd[q] = pcnd[q] & 1;
+            cpos[q] = pcnd[q] >> 1;                           // 1 + position in the row's compact block, 0: not a latent entry
             valid[q] = idx[q] >= 0;
             poison[q] = false;                                // non-finite coordinate => NaN block => "Cholesky failed"
             nugraw[q] = 0.0;
@@ -1273,6 +1274,15 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 }
             }
         }
+        if (A.Cout != nullptr) {
+            // posterior pass: the row's latent entries go straight into its compact block (entry e at block + 1 + e; the head
+            // gets a_k below), 16 bytes each; one broadcast load of the block offset per set
+            const int64_t cb = set_on ? (int64_t)A.cboff[A.rowid[k]] : 0;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+                if (set_on && row[q] < P && valid[q] && cpos[q] != 0)
+                    A.Cout[cb + cpos[q]] = make_double2(x[q], A.Cboth ? x[q] : 0.0);
+        }
         if (A.flags & 6) {
             double negmu;                              // -mu_k = -sum_j b_j z_j over observed-conditioned neighbours
             if constexpr (ZROW) {
@@ -1294,6 +1304,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const double tau = nugraw[QO];
                 const double zk = zi[QO];
                 if (A.aout != nullptr && set_on && i == IO) A.aout[A.rowid[k]] = fail ? 0.0 : negmu * rs;
+                if (A.Cout != nullptr && set_on && i == IO)
+                    A.Cout[A.cboff[A.rowid[k]]] = make_double2(fail ? 0.0 : negmu * rs, 0.0);
                 if (A.flags & 2) {
                     const double tv = tau + vlast;
                     const double rz = zk + negmu;                    // z_k - mu_k

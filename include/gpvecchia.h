@@ -49,7 +49,9 @@ enum {
     GPV_WANT_LOGLIK_Z = 2, /* fused cond.yz='z' log-likelihood sums (needs gpv_plan_set_data) */
     GPV_WANT_NUMERATOR = 4,/* numerator sums of R/vecchia_likelihood.R:74-76 for any cond.yz  */
     GPV_WANT_DENOM = 8,    /* + posterior pass (U2V) on the GPU for cond.yz='SGV': sums[2] = log det W, sums[3] = quadform.denom
-                              (R/vecchia_likelihood.R:85-90); needs gpv_plan_build_posterior; implies WANT_U|WANT_NUMERATOR.
+                              (R/vecchia_likelihood.R:85-90); needs gpv_plan_build_posterior; implies WANT_NUMERATOR.  The U
+                              entries are materialised (gpv_plan_get_Lentries) only when GPV_WANT_U is asked for as well: the
+                              kernel hands the latent entries to the posterior pass directly.
                               Nuggets must be > 0 (+Inf = unobserved is fine): a zero nugget makes W infinite and the sums NaN;
                               the reference removes such rows on the host first (R/createU.R:173-193) */
     GPV_WANT_MEAN = 16,    /* + posterior mean of the latent field in ORDERED layout, mu.ord of R/vecchia_prediction.R:118-126
