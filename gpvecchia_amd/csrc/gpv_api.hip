@@ -325,6 +325,7 @@ struct gpv_plan {
     bool post_fused = false;                         // the set kernel writes the compact blocks itself (block positions in d_cond)
     int post_ld = 0;                                 // bound of the entries per column of the posterior structure (>= P; more with fill)
     uint8_t *d_cslot = nullptr;
+    double *d_avec_base = nullptr;                   // allocation of d_avec: 64 bytes of header, then the n values
     double *d_avec = nullptr, *d_tvec = nullptr, *d_rdiag = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
     std::vector<int32_t> levptr, levptr2;
@@ -421,7 +422,7 @@ int gpv_plan_destroy(gpv_plan *pl)
     void *ptrs[] = {pl->d_locs, pl->d_nuggets, pl->d_nug_user, pl->d_z, pl->d_L, pl->d_block, pl->d_sums,
                     pl->d_Z, pl->d_tmp, pl->d_covvals, pl->d_stage, pl->d_nn, pl->d_newpos, pl->d_rowid, pl->d_cond,
                     pl->d_colptr, pl->d_crow, pl->d_colrec, pl->d_rowrec, pl->d_cslot,
-                    pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
+                    pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec_base, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket,
                     pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec};
@@ -730,6 +731,7 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
 static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nuggets, int64_t n_nuggets, int flags,
                           void *stream_v, double *d_sums_out)
 {
+    flags &= 63;                                                  // (the bits above are the kernels' own)
     if (flags & GPV_WANT_MEAN) flags |= GPV_WANT_DENOM;
     const bool mean_b = (flags & GPV_WANT_MEAN_B) != 0;
     if (mean_b && (flags & GPV_WANT_DENOM)) return GPV_ERR_BAD_ARG;      // one posterior pass per evaluation
@@ -778,9 +780,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.Lentries = (flags & GPV_WANT_U) ? pl->d_L : nullptr;
     a.aout = (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) ? pl->d_avec : nullptr;
     const bool fused = (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) && pl->post_fused;
-    a.Cout = fused ? pl->d_C : nullptr;
-    a.cboff = fused ? pl->d_cboff : nullptr;
-    a.Cboth = mean_b ? 1 : 0;
+
     a.block_sums = pl->d_block;
     a.sums = pl->d_sums;
     // with a communicator attached the totals of THIS rank stay in d_sums, RCCL sums them over the ranks in place on the
@@ -806,7 +806,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.locs_ld = pl->locs_ld;
     a.dim = pl->dim;
     a.cov = cs.cov;
-    a.flags = flags;
+    a.flags = flags | (fused ? kFlagFused : 0) | ((fused && mean_b) ? kFlagBoth : 0);
     a.sig0 = cs.sig0; a.sA = cs.sA; a.cA = cs.cA; a.sB = cs.sB; a.cB = cs.cB;
     // The Matern kernels multiply the coordinates by cA = sqrt(2 nu)/range once per row instead of the distance once per
     // pair.  Where c * |x| would overflow (range below 1e-300 of the coordinates' magnitude) the reference's own dist/range
@@ -1408,7 +1408,14 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         ++pl->mean_head_levels;
     if (pl->mean_head_levels < 4) pl->mean_head_levels = 0;            // not worth a launch of its own
     const size_t nd = sizeof(double) * (size_t)n;
-    if (!pl->d_avec) GPV_HIP(hipMalloc((void **)&pl->d_avec, nd));
+    if (!pl->d_avec_base) {
+        GPV_HIP(hipMalloc((void **)&pl->d_avec_base, nd + 64));
+        pl->d_avec = pl->d_avec_base + 8;                              // 64 bytes of header in front (SetArgs::aout)
+    }
+    {
+        const unsigned long long hdr[4] = {(unsigned long long)(uintptr_t)pl->d_C, (unsigned long long)(uintptr_t)pl->d_cboff, 0ull, 0ull};
+        GPV_HIP(hipMemcpy(pl->d_avec - 4, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+    }
     if (!pl->d_nug_post) GPV_HIP(hipMalloc((void **)&pl->d_nug_post, 64));
     for (auto &g : pl->pgraph)                                         // the schedule may have changed
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
@@ -1417,7 +1424,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     if (!pl->d_u) GPV_HIP(hipMalloc((void **)&pl->d_u, nd));
     if (!pl->d_mu) GPV_HIP(hipMalloc((void **)&pl->d_mu, nd));
     if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 512));
-    if (!pl->d_L) GPV_HIP(hipMalloc((void **)&pl->d_L, nd * pl->P));
+    if (!pl->d_L && !pl->post_fused) GPV_HIP(hipMalloc((void **)&pl->d_L, nd * pl->P));   // (fused: only when the caller wants U)
     pl->have_post = true;
     return GPV_OK;
 }

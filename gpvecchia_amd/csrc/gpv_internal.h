@@ -13,6 +13,9 @@ namespace gpv {
 enum CovKind : int { COV_MATERN05 = 0, COV_MATERN15 = 1, COV_MATERN25 = 2, COV_ESQE = 3, COV_DENSE = 4, COV_MATERN_GEN = 5 };
 
 constexpr int kNSums = 8;      // GPV_NSUMS
+// internal bits of SetArgs::flags (above the public GPV_WANT_* bits 1 .. 32)
+constexpr int kFlagFused = 64;    // deposit the compact blocks of the posterior pass (see SetArgs::aout)
+constexpr int kFlagBoth = 128;    //   as (B, B) instead of (B, 0) (cond.yz = 'zy': R := B)
 constexpr int kMaxDimGeneric = 8;
 constexpr int kMaxGrid = 16384;   // upper bound of the conditioning-set grid (block_sums is sized for it)
 
@@ -29,9 +32,11 @@ struct SetArgs {
     const double *covvals;   // COV_DENSE: [Nlocs][Nlocs] symmetric covariance (U_NZentries_mat) or nullptr
     double *Lentries;        // [rows][P] row-major, left-aligned, or nullptr
     double *aout;            // [rows] a_k = sum_j M_j z_j over observed-conditioned neighbours (R/vecchia_likelihood.R:74) or nullptr
-    double2 *Cout;           // posterior pass: the compact (B, R) blocks; the kernel deposits the latent entries of every row (and a_k)
-    const int32_t *cboff;    //   straight into the row's block at Cout[cboff[row]] (no Lentries round trip, no compaction launch), or nullptr
-    int Cboth;               //   1: (B, B) instead of (B, 0) (cond.yz = 'zy': R := B)
+                             // With kFlagFused in `flags` the kernel also deposits the latent entries of every row (and a_k) straight
+                             // into the row's compact (B, R) block of the posterior pass, at C[cboff[row]]: no Lentries round trip, no
+                             // compaction launch.  The two addresses sit in the 32 bytes IN FRONT of aout ({C, cboff, -, -}: read once
+                             // per task where they are used; as kernel arguments they were five more SGPRs live through the whole task
+                             // loop, which tipped the general-nu instantiation into reloading spilled SGPRs inside the rounds).
     double *block_sums;      // [grid][kNSums] per-workgroup partial sums
     double *sums;            // [kNSums] their fixed-order total, written by the workgroup that finishes last (gpv_reduce_tail.hpp)
     double *sums_copy;       // second destination of the totals (the caller's all-reduce buffer) or nullptr

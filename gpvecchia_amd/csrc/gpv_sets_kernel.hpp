@@ -560,12 +560,16 @@ __device__ __forceinline__ void matern_table_fetch(const SetArgs &A, const doubl
         }
     }
 }
-__device__ __forceinline__ double matern_table_value(const double (&r)[MaternTab::ROW], double s, const ExpScaled &E)
+// exp(-s) for the arguments beyond the folded rows: ONE out-of-line copy.  Inlined at the 30 places of the rounds its eleven
+// coefficients wanted 22 SGPRs through the whole kernel, and the general-nu instantiation is short of exactly those (it
+// reloaded spilled SGPRs inside the rounds); the call sits in a branch a wave takes only with an argument >= 4.
+static __device__ __attribute__((noinline)) double exp_neg_cold(double s) { return exp_neg(s); }
+__device__ __forceinline__ double matern_table_value(const double (&r)[MaternTab::ROW], double s)
 {
     const double pv = matern_tab_poly(r, s);
     // below s = 4 the row is the covariance (exp(-s) folded in, gpv_bessel.hpp); a wave with an argument beyond pays for exp
     if (__builtin_amdgcn_ballot_w64(s >= GPV_MT_FOLD_BELOW) == 0) return pv;
-    return s >= GPV_MT_FOLD_BELOW ? pv * exp_neg_scaled(s, E) : pv;   // E: scale 1 (normcon is in the table)
+    return s >= GPV_MT_FOLD_BELOW ? pv * exp_neg_cold(s) : pv;       // (normcon is in the table)
 }
 
 // General nu, the pairs the table did not cover (bit s - 1 of `need`: the pair of row rq and its partner of round s), exactly:
@@ -645,7 +649,7 @@ __device__ __forceinline__ double cov_closed(double r2, double sig0, double sA, 
     if constexpr (COV == COV_MATERN_GEN) {
         double sg, r[MaternTab::ROW];
         const bool live = gen_fetch<MTW, SCALED, R2MIN>(r2, cA, A, mt_lds, sg, r, need, bit, pair_used);
-        const double v = matern_table_value(r, sg, E);
+        const double v = matern_table_value(r, sg);
         return live ? v : sig0;                                      // src/Matern.cpp:76
     }
     if constexpr (!R2MIN) r2 = __builtin_fmax(r2, 2.2250738585072014e-308);
@@ -699,7 +703,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 
     const double sig0 = A.sig0, sA = A.sA, cA = A.cA, sB = A.sB, cB = A.cB;
     // closed-form Matern families: sigma^2 exp(-t) (cov_closed); general nu: the table carries the constant factor
-    const ExpScaled expS = exp_scaled_setup<(COV == COV_MATERN_GEN && GPV_OPT_GEN_SGPR != 0)>(COV == COV_MATERN_GEN ? 1.0 : sA);
+    const ExpScaled expS = exp_scaled_setup<false>(COV == COV_MATERN_GEN ? 1.0 : sA);   // (general nu: unused, exp_neg_cold)
     const unsigned long long setmask = (LPS == 64) ? ~0ull : (((1ull << LPS) - 1ull) << (sub * LPS));
 
     for (int q = lane; q < SPW * kNSums; q += 64) (&L.acc[0][0])[q] = 0.0;
@@ -772,7 +776,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         asm volatile("" : "+v"(i));
 
         // ---- gather: indices, cond flags, coordinates, nugget, data -------------------
-        int row[RPL], idx[RPL], cnd[RPL], cpos[RPL], wslot[RPL];
+        int row[RPL], idx[RPL], cndraw[RPL], wslot[RPL];     // cndraw: the cond byte as stored (flag in bit 0, block position above it)
         bool valid[RPL], poison[RPL];
         double xi[RPL][(D == 0) ? 1 : D];
         double nugraw[RPL], zi[RPL];
@@ -782,8 +786,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             row[q] = i + q * LPS;
             wslot[q] = lane_on ? row[q] : COLS - 1;          // idle lanes write to the dump slot: no branches in the sweep
             idx[q] = pidx[q];
-            cnd[q] = pcnd[q] & 1;
-            cpos[q] = pcnd[q] >> 1;                           // 1 + position in the row's compact block, 0: not a latent entry
+            cndraw[q] = pcnd[q];
             valid[q] = idx[q] >= 0;
             poison[q] = false;                                // non-finite coordinate => NaN block => "Cholesky failed"
             nugraw[q] = 0.0;
@@ -997,7 +1000,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     if (s < H) stage_a(s + 1);
 #pragma unroll
                     for (int q = 0; q < RPL; ++q) {
-                        double v = matern_table_value(rc[q], sgc[q], expS);
+                        double v = matern_table_value(rc[q], sgc[q]);
                         v = livec[q] ? v : sig0;                     // src/Matern.cpp:76 (a select, not a branch round the polynomial)
                         if constexpr (MASKED) v = usedc[q] ? v : 0.0;
                         *lds_wptr(((rq[q] < P - s) ? trA[q] : trB[q]) + 8 * s) = v;
@@ -1072,7 +1075,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         for (int q = 0; q < RPL; ++q) {
             double diag;
             if constexpr (COV == COV_DENSE) diag = valid[q] ? A.covvals[(int64_t)idx[q] * A.nlocs + idx[q]] : 1.0;
-            else diag = valid[q] ? (sig0 + nugraw[q] * (1.0 - (double)cnd[q])) : 1.0;   // src/U_NZentries.cpp:47,52
+            else diag = valid[q] ? (sig0 + nugraw[q] * (1.0 - (double)(cndraw[q] & 1))) : 1.0;   // src/U_NZentries.cpp:47,52
             if (poison[q]) diag = __builtin_nan("");
             // an Inf (or absurdly large) nugget behaves like 2^990: its multipliers vanish below rounding either way, and
             // no pivot (a Schur complement, at most its diagonal entry) can then overflow the reciprocal; NaN stays NaN
@@ -1080,7 +1083,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             if (lane_on && row[q] < P) {
                 L.tri[sub][(int)(__umul24(row[q], row[q] + 1) >> 1) + row[q]] = diag;
                 // data row: z_j of the neighbours conditioned on as observations (R/vecchia_likelihood.R:74)
-                if (ZROW) L.col[Lds::NCOL - 1][sub][row[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? zi[q] : 0.0;
+                if (ZROW) L.col[Lds::NCOL - 1][sub][row[q]] = (valid[q] && (cndraw[q] & 1) == 0 && row[q] != P - 1) ? zi[q] : 0.0;
             }
         }
         wave_sync();
@@ -1274,14 +1277,21 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 }
             }
         }
-        if (A.Cout != nullptr) {
+        const bool fused = (A.flags & kFlagFused) != 0;
+        double2 *Cout = nullptr;
+        int64_t cb = 0;
+        if (fused) {
             // posterior pass: the row's latent entries go straight into its compact block (entry e at block + 1 + e; the head
-            // gets a_k below), 16 bytes each; one broadcast load of the block offset per set
-            const int64_t cb = set_on ? (int64_t)A.cboff[A.rowid[k]] : 0;
+            // gets a_k below), 16 bytes each; the two addresses come from the header in front of aout
+            const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(A.aout) - 4;
+            Cout = reinterpret_cast<double2 *>(hdr[0]);
+            const int32_t *cboff = reinterpret_cast<const int32_t *>(hdr[1]);
+            cb = set_on ? (int64_t)cboff[A.rowid[k]] : 0;
+            const bool both = (A.flags & kFlagBoth) != 0;
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
-                if (set_on && row[q] < P && valid[q] && cpos[q] != 0)
-                    A.Cout[cb + cpos[q]] = make_double2(x[q], A.Cboth ? x[q] : 0.0);
+                if (set_on && row[q] < P && valid[q] && (cndraw[q] >> 1) != 0)     // (1 + position in the block; 0: not latent)
+                    Cout[cb + (cndraw[q] >> 1)] = make_double2(x[q], both ? x[q] : 0.0);
         }
         if (A.flags & 6) {
             double negmu;                              // -mu_k = -sum_j b_j z_j over observed-conditioned neighbours
@@ -1292,7 +1302,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 double *cb = L.col[(P & 1) & (Lds::NCOL - 1)][sub];
 #pragma unroll
                 for (int q = 0; q < RPL; ++q)
-                    cb[wslot[q]] = (valid[q] && cnd[q] == 0 && row[q] != P - 1) ? x[q] * zi[q] : 0.0;
+                    cb[wslot[q]] = (valid[q] && (cndraw[q] & 1) == 0 && row[q] != P - 1) ? x[q] * zi[q] : 0.0;
                 wave_sync();
                 double ak = 0.0;
 #pragma unroll
@@ -1304,8 +1314,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const double tau = nugraw[QO];
                 const double zk = zi[QO];
                 if (A.aout != nullptr && set_on && i == IO) A.aout[A.rowid[k]] = fail ? 0.0 : negmu * rs;
-                if (A.Cout != nullptr && set_on && i == IO)
-                    A.Cout[A.cboff[A.rowid[k]]] = make_double2(fail ? 0.0 : negmu * rs, 0.0);
+                if (fused && set_on && i == IO) Cout[cb] = make_double2(fail ? 0.0 : negmu * rs, 0.0);
                 if (A.flags & 2) {
                     const double tv = tau + vlast;
                     const double rz = zk + negmu;                    // z_k - mu_k

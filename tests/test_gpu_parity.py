@@ -585,10 +585,11 @@ revNN = NN[:, ::-1].copy()
 revCond = np.where(revNN != 0, 0, -1).astype(np.int8); revCond[:, -1] = 1
 plan = G.Plan(locs, revNN, revCond); plan.set_data(z)
 out = {{}}
-for nu in (0.3, 1.1, 7.7, 24.0):
-    plan.eval("matern", [1.3, 0.09, nu], 0.05, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
+# (range 0.09: every s = dist/range below 4, the rows carry exp(-s); range 0.004: s from 2 to 50, exp(-s) out of line)
+for nu, rng_ in ((0.3, 0.09), (1.1, 0.09), (7.7, 0.09), (24.0, 0.09), (1.1, 0.004), (0.4, 0.01)):
+    plan.eval("matern", [1.3, rng_, nu], 0.05, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
     L = plan.Lentries()
-    out[str(nu)] = [G.loglik_z_from_sums(plan.sums(), n), float(np.abs(L).sum()), float(L[n // 2, 3])]
+    out["%s/%s" % (nu, rng_)] = [G.loglik_z_from_sums(plan.sums(), n), float(np.abs(L).sum()), float(L[n // 2, 3])]
 print("ROUTE " + json.dumps(out))
 """
 
