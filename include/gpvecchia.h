@@ -308,7 +308,7 @@ int gpv_mplan_vl_get_one(gpv_mplan *mplan, int replica, double *mean_ord, double
  *   id128: 128 bytes (ncclUniqueId); rank 0 fills it with gpv_comm_unique_id and hands it to the other ranks by whatever
  *          channel the launcher offers (MPI_Bcast, a torch.distributed store, a file);
  *   gpv_comm_create is collective: it returns when all `world` ranks have called it with the same id;
- *   gpv_plan_set_comm(plan, NULL) detaches.  Flags with a communicator: GPV_WANT_U | GPV_WANT_LOGLIK_Z |
+ *   gpv_plan_set_comm(plan, NULL) detaches; detach (or destroy) every plan before gpv_comm_destroy.  Flags with a communicator: GPV_WANT_U | GPV_WANT_LOGLIK_Z |
  *   GPV_WANT_NUMERATOR (the posterior pass does not shard: GPV_ERR_STATE). */
 typedef struct gpv_comm gpv_comm;
 int gpv_comm_unique_id(void *id128);
