@@ -686,6 +686,17 @@ def test_totals_by_sequence_number_and_by_stream_wait_interleave():
             plan.eval("matern", par[0], par[1], fl)
             np.testing.assert_array_equal(plan.sums(), want[tag, fl])
             np.testing.assert_array_equal(plan.sums(), want[tag, fl])          # a second read finds the same number
+    # the posterior pass takes its entries from the set kernel directly: U is materialised only on request
+    plan.eval("matern", pA[0], pA[1], F_post)
+    with pytest.raises(G.GpvError) as e:
+        plan.Lentries()
+    assert e.value.status == 7
+    plan.eval("matern", pA[0], pA[1], F_post | G.GPV_WANT_U)
+    np.testing.assert_array_equal(plan.sums(), want["A", F_post])
+    Lp = plan.Lentries()
+    ref = make()
+    ref.eval("matern", pA[0], pA[1], G.GPV_WANT_U)
+    np.testing.assert_array_equal(Lp, ref.Lentries())
 
 
 @pytest.mark.parametrize("covmodel,cp", [("matern", [1.3, 0.2, 0.5]), ("matern", [1.3, 0.2, 1.5]), ("matern", [0.7, 0.2, 2.5]),
