@@ -1278,20 +1278,25 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             }
         }
         const bool fused = (A.flags & kFlagFused) != 0;
-        double2 *Cout = nullptr;
+        typedef double v2d_out __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) v2d_out gl_v2d;
+        gl_v2d *Cout = nullptr;
         int64_t cb = 0;
         if (fused) {
             // posterior pass: the row's latent entries go straight into its compact block (entry e at block + 1 + e; the head
             // gets a_k below), 16 bytes each; the two addresses come from the header in front of aout
+            // (addresses read from memory carry no address space: say "global", or the accesses are FLAT instructions, whose
+            // completion the compiler can only wait for with vmcnt(0) & lgkmcnt(0))
             const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(A.aout) - 4;
-            Cout = reinterpret_cast<double2 *>(hdr[0]);
-            const int32_t *cboff = reinterpret_cast<const int32_t *>(hdr[1]);
+            Cout = reinterpret_cast<gl_v2d *>(hdr[0]);
+            typedef __attribute__((address_space(1))) const int32_t gl_cint;
+            const gl_cint *cboff = reinterpret_cast<const gl_cint *>(hdr[1]);
             cb = set_on ? (int64_t)cboff[A.rowid[k]] : 0;
             const bool both = (A.flags & kFlagBoth) != 0;
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
                 if (set_on && row[q] < P && valid[q] && (cndraw[q] >> 1) != 0)     // (1 + position in the block; 0: not latent)
-                    Cout[cb + (cndraw[q] >> 1)] = make_double2(x[q], both ? x[q] : 0.0);
+                    Cout[cb + (cndraw[q] >> 1)] = v2d_out{x[q], both ? x[q] : 0.0};
         }
         if (A.flags & 6) {
             double negmu;                              // -mu_k = -sum_j b_j z_j over observed-conditioned neighbours
@@ -1314,7 +1319,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const double tau = nugraw[QO];
                 const double zk = zi[QO];
                 if (A.aout != nullptr && set_on && i == IO) A.aout[A.rowid[k]] = fail ? 0.0 : negmu * rs;
-                if (fused && set_on && i == IO) Cout[cb] = make_double2(fail ? 0.0 : negmu * rs, 0.0);
+                if (fused && set_on && i == IO) Cout[cb] = v2d_out{fail ? 0.0 : negmu * rs, 0.0};
                 if (A.flags & 2) {
                     const double tv = tau + vlast;
                     const double rz = zk + negmu;                    // z_k - mu_k
