@@ -421,7 +421,8 @@ def main():
         def step():
             if comm is not None:
                 # N > 1 (one process per GPU): the library enqueues kernel, RCCL all-reduce of the 8 sums (64 bytes over xGMI)
-                # and their copy to pinned host memory on this one stream; sums() spins on the event behind the copy
+                # and the 64-thread kernel that stores them into pinned host memory on this one stream; sums() spins on the
+                # sequence number behind them
                 plan.eval("matern", covparms, tau, flags, stream=stream)
                 host = plan.sums()
                 return G.loglik_z_from_sums(host, n)

@@ -818,9 +818,9 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         static const bool no_tab = getenv("GPV_NO_MATERN_TABLE") != nullptr;
         if (!no_tab && pl->dist_min > 0.0 && pl->dist_max >= pl->dist_min) {
             constexpr int kMaxSeg = 80 * MaternTab::SPO;                   // 80 octaves
-            // the table travels in kernel-argument style: two pinned host staging buffers and two device copies used
-            // alternately, guarded by an event each, so that building the table for this evaluation never waits for the
-            // stream (the previous evaluation may still be reading the other copy)
+            // two device copies of the table used alternately (and, for the host fit GPV_MATERN_TABLE_HOST=1 only, two pinned
+            // staging buffers guarded by an event each, so that filling one never waits for the stream: the previous
+            // evaluation may still be reading the other copy)
             const size_t tabb = sizeof(double) * kMaxSeg * MaternTab::ROW;
             const int sl = pl->mt_slot ^= 1;
             if (!pl->h_mt2[sl]) {
