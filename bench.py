@@ -75,9 +75,11 @@ def build_workload(n, m, d, rank, world, seed=0, device=0):
     return locs, z, revNN, revCond, a, b
 
 
-def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3):
+def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, keep=None):
     """Time the oracle's C restatement of U_NZentries (OpenMP, all host cores) on the conditioning sets
-    [a, b) of the SAME workload (the whole data set when it fits the time budget)."""
+    [a, b) of the SAME workload (the whole data set when it fits the time budget).  keep: a dict that receives the
+    oracle's U entries of those sets (`Lentries`, rows a..b-1) for the parity_in_run block — the checker's output is
+    compared with the GPU's, never fed back into it."""
     from oracle import r_side as R
     a, b = rows_sample
     n = locs.shape[0]
@@ -103,8 +105,13 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3):
     times = []
     for _ in range(repeats):
         t0 = time.perf_counter()
-        R.U_NZentries(cores, 1, lp, nnp, cdp, nug, nug[:1], "matern", covparms)
+        ref = R.U_NZentries(cores, 1, lp, nnp, cdp, nug, nug[:1], "matern", covparms)
         times.append(time.perf_counter() - t0)
+    if keep is not None:
+        keep["Lentries"] = ref["Lentries"][: b - a]
+        keep["n_failed"] = ref["n_failed"]
+        keep["rows"] = (a, b)
+    del ref
     t = float(np.median(times))
     sets_per_s = (b - a) / t
     if full:
@@ -118,6 +125,28 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3):
                 extrapolated=not full, sets_per_s=sets_per_s, seconds=t,
                 note="own C restatement of src/U_NZentries.cpp:39-69 without Armadillo's per-iteration temporaries: "
                      "FASTER than the real reference (BASELINE.md §2), which cannot be built on this box")
+
+
+def parity_in_run(gpu_L, gpu_loglik, gpu_nfail, kept, revNN, z, tau, n):
+    """The bench run's own parity evidence (outside every timed region): the U entries the GPU wrote for this workload
+    (one GPV_WANT_U evaluation) against the oracle's — the rows the cpu_baseline leg computed anyway — row by row,
+    normwise, and the log-likelihood against the oracle's (closed form of R/vecchia_likelihood.R:63-99 for cond.yz='z')."""
+    from oracle import r_side as R
+    a, b = kept["rows"]
+    ref = kept["Lentries"]
+    out = gpu_L[a:b]
+    err = np.abs(out - ref).max(axis=1) / np.maximum(np.abs(ref).max(axis=1), 1e-300)
+    res = {"rows_compared": int(b - a), "max_row_err": float(err.max()), "median_row_err": float(np.median(err)),
+           "n_failed": int((~(err <= 1e-8)).sum()), "tol": 1e-8,
+           "zero_pattern_equal": bool(np.array_equal(out == 0, ref == 0)),
+           "chol_failures": {"hip": int(gpu_nfail), "oracle": int(kept["n_failed"])},
+           "what": "U entries (Lentries) of the HIP path vs oracle/u_nzentries_oracle.c on the same inputs, per row "
+                   "max|dM|/max|M|; n_failed = rows beyond 1e-8; the oracle is a restatement (parity unpinned, DESIGN.md §3)"}
+    if a == 0 and b == n:
+        ll_o, _ = R.separable_sums_condz_vectorised(revNN, ref, z, tau)
+        res.update(loglik_oracle=float(ll_o), loglik_hip=float(gpu_loglik),
+                   loglik_rel_err=float(abs(gpu_loglik - ll_o) / abs(ll_o)))
+    return res
 
 
 def _free_port():
@@ -321,8 +350,12 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=1,
                     help="developer/secondary measurement: this rank takes the row shard rank 0 of a job of that many ranks "
                          "would own (rows = n / E) while the collectives run over the real world; NOT a scaling number")
-    ap.add_argument("--self-check", action="store_true",
-                    help="N > 1: rank 0 also evaluates the unsharded plan and asserts the N-rank log-likelihood equals it to 1e-12")
+    ap.add_argument("--self-check", action="store_true", help="(default for N > 1; kept for old command lines)")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="N > 1: skip rank 0's evaluation of the unsharded plan (by default it runs after the timed region and "
+                         "the N-rank log-likelihood must equal it to 1e-12; exit 3 otherwise)")
+    ap.add_argument("--comm-guard-s", type=float, default=300.0,
+                    help="N > 1: wall-clock limit for communicator creation + the first all-reduced evaluation (exit 4 beyond it)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -371,16 +404,27 @@ def main():
     # the collective of the step belongs to the library (gpv_comm: RCCL bound at run time, include/gpvecchia.h); torch.distributed
     # is the launcher, the rendezvous that carries the communicator's id, and the barrier / max-over-ranks of the timing.
     # GPV_TORCH_ALLREDUCE=1: the round-2 route (dist.all_reduce on the plan's device buffer), kept for A/B
-    comm = None
-    if use_dist and backend == "nccl" and os.environ.get("GPV_TORCH_ALLREDUCE", "0") != "1" and args.mode != "S":
-        try:
-            comm = G.Comm.from_torch(local_rank)
-        except Exception as e:                                    # e.g. no RCCL to bind: say so, then agree on the route below
-            print(f"[bench] rank {rank}: library communicator unavailable ({e!r}); dist.all_reduce instead", file=sys.stderr)
-        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)                 # every rank takes the same route
-        if int(ok.item()) == 0:
-            comm = None
+    comm, route = None, ("none (1 rank, no launcher)" if not use_dist else f"torch.distributed all_reduce ({backend})")
+    guard = None
+    if use_dist and backend == "nccl" and args.mode != "S":
+        # Wall-clock guard around the first contact with N ranks: creating the communicator and the first all-reduced
+        # evaluation must finish within --comm-guard-s, else this rank says why and exits non-zero (the launcher then ends
+        # the others): a hung collective must not look like a slow bench.  Disarmed after the first complete step.
+        import threading
+
+        def _expired():
+            print(f"[bench] rank {rank}: no complete all-reduced evaluation within {args.comm_guard_s:.0f} s of starting the "
+                  f"communicator (route so far: {route}); exiting 4.  GPV_TORCH_ALLREDUCE=1 selects the torch.distributed route.",
+                  file=sys.stderr, flush=True)
+            os._exit(4)
+        guard = threading.Timer(args.comm_guard_s, _expired)
+        guard.daemon = True
+        guard.start()
+        from gpvecchia_amd.distributed import negotiate_comm
+        comm, why = negotiate_comm(local_rank, None, timeout_s=min(120.0, args.comm_guard_s / 2),
+                                   log=lambda m: print(f"[bench] rank {rank}: {m}", file=sys.stderr, flush=True))
+        route = ("library-owned RCCL communicator (gpv_comm), all-reduce enqueued by gpv_plan_eval; " + why) if comm is not None \
+            else f"torch.distributed all_reduce (nccl); gpv_comm not used: {why}"
 
     ci, n, m, d, nu, rng_ = CONFIGS[args.config]
     custom = any(v is not None for v in (args.n, args.m, args.d, args.nu))
@@ -406,6 +450,8 @@ def main():
     pinned = torch.zeros(G._lib.NSUMS, dtype=torch.float64).pin_memory()
     done = torch.cuda.Event()
 
+    last_sums = np.zeros(G._lib.NSUMS)                    # the totals of the latest step (N > 1: after the all-reduce)
+
     def fence():
         torch.cuda.synchronize()
         if use_dist:
@@ -425,6 +471,7 @@ def main():
                 # sequence number behind them
                 plan.eval("matern", covparms, tau, flags, stream=stream)
                 host = plan.sums()
+                last_sums[:] = host
                 return G.loglik_z_from_sums(host, n)
             if use_dist:
                 plan.eval("matern", covparms, tau, flags, stream=stream, d_sums_out=sums.data_ptr())
@@ -441,14 +488,26 @@ def main():
                 # waits for the stream)
                 plan.eval("matern", covparms, tau, flags, stream=stream)
                 host = plan.sums()
+            last_sums[:] = host
             return G.loglik_from_sums(host, n) if denom else G.loglik_z_from_sums(host, n)
+        nonlocal guard
         ll = None
+        if guard is not None:
+            step()                                                # first contact: the first all-reduced evaluation of the job
+            guard.cancel()
+            guard = None
         # like timeit: no cyclic-GC pass inside the timed region (with torch imported a full collection walks millions of
         # objects: one 55 ms pause was seen in a 70 ms region of 0.18 ms steps; tools/comm_diag.py).  Collected HERE, before the
         # clock warm-up: a collection between the warm-up and the timed steps idles the GPU for ~40 ms and the clock is down again
         import gc
         gc.collect()
         gc.disable()
+        try:
+            return _measure_gc_off(step, plan, steps, warmup, cw_s, ll)
+        finally:
+            gc.enable()                                           # also when a step raises
+
+    def _measure_gc_off(step, plan, steps, warmup, cw_s, ll):
         # clock warm-up (untimed, before the W warm-up steps): the GPU's power management drops the shader clock within
         # milliseconds of idling and takes ~35 ms of continuous work to bring it back (tools/clock_ramp.py,
         # profiles/r03_clock_ramp.txt: 1.46 -> 1.26 ms per launch over the first 25 launches at this workload); a timed region of 20
@@ -482,7 +541,6 @@ def main():
                   f"over 2x median: {int((dt > 2 * np.median(dt)).sum())}; first 5: {np.round(dt[:5], 1)}", file=sys.stderr)
         fence()
         el = time.perf_counter() - t0
-        gc.enable()
         return el, (float(np.mean(kms)) if kms else float("nan")), ll
 
     def roofline(k_ms, rows_rank, mode, traffic=None):
@@ -549,16 +607,32 @@ def main():
         all_reduce_(km, dist.ReduceOp.MAX)
         k_ms = float(km.item())
 
+    sums_job = last_sums.copy()                           # totals of the last timed step (N > 1: all-reduced over the ranks)
+    gpu_U = None
+    if world == 1 and not use_dist and args.mode == "L" and not args.no_cpu_baseline and p <= 64:
+        # parity_in_run, GPU half (untimed): one more evaluation that also writes the U entries, copied to the host
+        plan.eval("matern", covparms, tau, flags | G.GPV_WANT_U, stream=stream)
+        s_u = plan.sums()
+        gpu_U = {"L": plan.Lentries(), "loglik": G.loglik_z_from_sums(s_u, n), "n_failed": int(s_u[6])}
+
+    # N > 1 proves itself (default; --no-self-check skips the second half): (1) the all-reduced row count sums[7] must equal n
+    # — every rank contributed its rows exactly once; (2) rank 0 evaluates the UNSHARDED plan after the timed region and the
+    # N-rank log-likelihood must equal it to 1e-12 (the shards only change the summation tree, src/U_NZentries.cpp:37-39)
     check = None
-    if args.self_check and world > 1 and rank == 0:
-        l1, z1, nn1, cd1, _, _ = build_workload(n, m, d, 0, 1, device=local_rank)
-        full = G.Plan(l1, nn1, cd1, device=local_rank)
-        full.set_data(z1)
-        full.eval("matern", covparms, tau, flags)
-        ll1 = G.loglik_z_from_sums(full.sums(), n)
-        del full
-        rel = abs(ll1 - loglik) / abs(ll1)
-        check = {"loglik_1rank": ll1, "loglik_nrank": loglik, "rel_diff": rel, "tol": 1e-12, "ok": bool(rel <= 1e-12)}
+    if world > 1 and rank == 0 and args.mode != "S":
+        check = {"rows_reduced": float(sums_job[7]), "rows_expected": n, "ranks": world,
+                 "rows_ok": bool(sums_job[7] == n), "chol_failures_reduced": float(sums_job[6])}
+        check["ok"] = check["rows_ok"]
+        if not args.no_self_check:
+            l1, z1, nn1, cd1, _, _ = build_workload(n, m, d, 0, 1, device=local_rank)
+            full = G.Plan(l1, nn1, cd1, device=local_rank)
+            full.set_data(z1)
+            full.eval("matern", covparms, tau, flags)
+            ll1 = G.loglik_z_from_sums(full.sums(), n)
+            del full, l1, z1, nn1, cd1
+            rel = abs(ll1 - loglik) / abs(ll1)
+            check.update(loglik_1rank=ll1, loglik_nrank=loglik, rel_diff=rel, tol=1e-12, loglik_ok=bool(rel <= 1e-12))
+            check["ok"] = bool(check["rows_ok"] and check["loglik_ok"])
         if not check["ok"]:
             print(f"[bench] self-check FAILED: {check}", file=sys.stderr)
 
@@ -592,9 +666,7 @@ def main():
                                       f"; THIS RANK'S SHARD of an emulated {args.emulate_world}-rank job only)"),
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
                        "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2),
-                       "collective": ("none (1 rank, no launcher)" if not use_dist else
-                                      "library-owned RCCL communicator (gpv_comm), all-reduce enqueued by gpv_plan_eval" if comm is not None
-                                      else f"torch.distributed all_reduce ({backend})")},
+                       "collective": route, "ranks": world, "rows_reduced": float(sums_job[7])},
             "roofline": roofline(k_ms, rows_rank, args.mode, traffic),
         }
         if from_idle is not None:
@@ -650,12 +722,18 @@ def main():
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.mode != "S":
             cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - min(b - a - 2 * p, 60000), b), repeats=2)
+            kept = {}
             if n / cal["sets_per_s"] <= args.cpu_budget_s:
-                out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (0, n), repeats=3)
+                out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (0, n), repeats=3, keep=kept)
             else:
                 sample = int(min(b - a - 2 * p, max(20000, cal["sets_per_s"] * args.cpu_budget_s)))
-                out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - sample, b), repeats=3)
+                out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - sample, b), repeats=3, keep=kept)
             out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+            if gpu_U is not None:
+                try:
+                    out["parity_in_run"] = parity_in_run(gpu_U["L"], gpu_U["loglik"], gpu_U["n_failed"], kept, revNN, z, tau, n)
+                except Exception as e:
+                    out["parity_in_run"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     rc = 0 if (check is None or check["ok"]) else 3
     if use_dist:

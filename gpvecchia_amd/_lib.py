@@ -37,7 +37,7 @@ EXPORTS = [
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
     "gpv_mplan_create_replicas", "gpv_mplan_count", "gpv_mplan_set_data_one", "gpv_mplan_build_posterior",
     "gpv_mplan_eval_each", "gpv_mplan_vl_begin_one", "gpv_mplan_vl_step_each", "gpv_mplan_vl_get_one",
-    "gpv_comm_unique_id", "gpv_comm_create", "gpv_comm_destroy", "gpv_plan_set_comm",
+    "gpv_rccl_version", "gpv_comm_unique_id", "gpv_comm_create", "gpv_comm_destroy", "gpv_plan_set_comm",
 ]
 
 

@@ -166,11 +166,15 @@ class Comm:
 
     def __init__(self, device, rank, world, exchange):
         ident = C.create_string_buffer(128)
+        st0 = L.lib().gpv_comm_unique_id(ident) if rank == 0 else 0
+        # rank 0 ALWAYS takes part in the exchange: if it could not make the id it hands out an empty one and every rank
+        # raises here, instead of rank 0 raising alone while the others wait for a broadcast that never comes
+        raw = exchange((bytes(ident.raw) if st0 == 0 else b"") if rank == 0 else None)
         if rank == 0:
-            L.check(L.lib().gpv_comm_unique_id(ident), "gpv_comm_unique_id")
-        raw = exchange(bytes(ident.raw) if rank == 0 else None)
+            L.check(st0, "gpv_comm_unique_id")
         if not isinstance(raw, (bytes, bytearray)) or len(raw) != 128:
-            raise ValueError("Comm: the exchange must hand every rank the 128 bytes of rank 0")
+            raise RuntimeError("Comm: rank 0 could not produce the communicator id (no RCCL to bind?)" if raw == b"" else
+                               "Comm: the exchange must hand every rank the 128 bytes of rank 0")
         ident = C.create_string_buffer(bytes(raw), 128)
         self._h = C.c_void_p()
         self.device, self.rank, self.world = int(device), int(rank), int(world)
@@ -178,6 +182,9 @@ class Comm:
 
     @classmethod
     def from_torch(cls, device, group=None):
+        """Collective over the torch group.  Raises on EVERY rank alike when rank 0 cannot produce the id; for a route that
+        is agreed between the ranks (and a fallback when the library's communicator is unavailable on any of them) use
+        gpvecchia_amd.distributed.negotiate_comm."""
         import torch.distributed as dist
         rank, world = dist.get_rank(group), dist.get_world_size(group)
 
@@ -186,6 +193,11 @@ class Comm:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             return box[0]
         return cls(device, rank, world, exchange)
+
+    @staticmethod
+    def rccl_version():
+        """ncclGetVersion() of the RCCL the library bound at run time; 0 when there is none (gpv_comm_* then return GPV_ERR_STATE)."""
+        return int(L.lib().gpv_rccl_version())
 
     def __del__(self):
         try:

@@ -60,6 +60,8 @@ struct RcclApi {
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    int version = 0;                               // ncclGetVersion's code (2.x.y: >= 2000); 0 = not bound
 };
 thread_local char g_rccl_text[200] = "";
 const RcclApi *rccl_api()
@@ -79,7 +81,13 @@ const RcclApi *rccl_api()
         api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
         api.AllReduce = (decltype(api.AllReduce))dlsym(api.handle, "ncclAllReduce");
         api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.handle, "ncclGetErrorString");
-        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { dlclose(api.handle); api = RcclApi{}; }
+        api.GetVersion = (decltype(api.GetVersion))dlsym(api.handle, "ncclGetVersion");
+        // the hand-declared prototypes above are those of NCCL >= 2.0 (ncclUniqueId by value, ncclDouble = 8, ncclSum = 0):
+        // refuse anything that cannot say it is that; gpv_comm_create then PROVES the ABI with one tiny all-reduce
+        int v = 0;
+        if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce || !api.GetVersion ||
+            api.GetVersion(&v) != 0 || v < 2000) { dlclose(api.handle); api = RcclApi{}; return; }
+        api.version = v;
     });
     return api.handle ? &api : nullptr;
 }
@@ -302,6 +310,7 @@ struct gpv_plan {
            *d_stage = nullptr;
     int32_t *d_nn = nullptr, *d_newpos = nullptr, *d_rowid = nullptr;
     unsigned *d_ticket = nullptr;                    // arrival counter of the set kernel's workgroups (gpv_reduce_tail.hpp)
+    bool ticket_dirty = false;                       // an evaluation failed after its launch may have started: reset before the next
     // pinned host mirror of the totals: when the caller names no device mirror, the kernels write the totals straight into
     // host memory and gpv_plan_get_sums needs no copy command, only the stream's completion
     void *h_stage[2] = {nullptr, nullptr};           // pinned staging of gpv_plan_get_Lentries (32 MB each, on first use)
@@ -795,7 +804,16 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     // appends the sequence number of this evaluation and gpv_plan_get_sums spins on it instead of waiting for the stream
     static const bool no_seq = getenv("GPV_NO_SEQ_HANDOFF") != nullptr;
     unsigned long long *const seq_cells = reinterpret_cast<unsigned long long *>(pl->h_sums_dev + kNSums);
-    const bool final_here = !(flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) && d_sums_out == nullptr && !no_seq;
+    // inside somebody's stream capture the sequence number would be frozen into the graph (every replay would publish the
+    // same one, and gpv_plan_get_sums would accept the previous replay's totals without waiting): wait for the stream there
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    const bool final_here = !(flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) && d_sums_out == nullptr && !no_seq &&
+                            cap == hipStreamCaptureStatusNone;
+    if (pl->ticket_dirty) {                        // the previous evaluation of this plan ended in an error: the arrival counter
+        GPV_HIP(hipMemsetAsync(pl->d_ticket, 0, 64, st));   // of its kernel may be non-zero (no workgroup would ever be "last")
+        pl->ticket_dirty = false;
+    }
     pl->sums_by_seq = final_here;
     if (final_here) ++pl->seq;
     a.seq_cells = (final_here && !cm) ? seq_cells : nullptr;
@@ -988,7 +1006,15 @@ int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int
     CovSetup cs;
     const int st = cov_setup(covType, covparms, ncovparms, cs);
     if (st != GPV_OK) return st;
-    return plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
+    const int rc = plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
+    if (rc != GPV_OK && rc != GPV_ERR_BAD_ARG) pl->ticket_dirty = true;   // a launch may have been cut short: reset the counter next time
+    return rc;
+}
+
+int gpv_rccl_version(void)
+{
+    const RcclApi *R = rccl_api();
+    return R ? R->version : 0;
 }
 
 int gpv_comm_unique_id(void *id128)
@@ -1018,6 +1044,31 @@ int gpv_comm_create(gpv_comm **out, int device, int rank, int world, const void 
     void *c = nullptr;
     const int rr = R->CommInitRank(&c, world, id, rank);   // collective: returns when every rank has joined
     if (rr != 0 || !c) return note_rccl(rr, "ncclCommInitRank");
+    // prove the communicator (and the hand-declared enum values) before any evaluation depends on it: all-reduce
+    // (1, rank + 1) as doubles with "sum"; every rank must read (world, world (world + 1) / 2)
+    {
+        double h[2] = {1.0, (double)(rank + 1)}, *d = nullptr;
+        hipStream_t ps = nullptr;
+        int bad = 0;
+        if (hipMalloc((void **)&d, sizeof(h)) != hipSuccess || hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess ||
+            hipMemcpy(d, h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess)
+            bad = 1;
+        int ar = 0;
+        if (!bad) ar = R->AllReduce(d, d, 2, /*ncclDouble*/ 8, /*ncclSum*/ 0, c, ps);
+        if (!bad && ar == 0 && (hipStreamSynchronize(ps) != hipSuccess || hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess))
+            bad = 1;
+        if (ps) (void)hipStreamDestroy(ps);
+        if (d) (void)hipFree(d);
+        const double want0 = (double)world, want1 = 0.5 * (double)world * (double)(world + 1);
+        if (bad || ar != 0 || h[0] != want0 || h[1] != want1) {
+            (void)R->CommDestroy(c);
+            if (ar != 0) return note_rccl(ar, "ncclAllReduce (probe)");
+            g_hip_code = 0;
+            std::snprintf(g_hip_text, sizeof(g_hip_text), "RCCL probe all-reduce over %d ranks returned (%g, %g), expected (%g, %g)",
+                          world, h[0], h[1], want0, want1);
+            return GPV_ERR_STATE;
+        }
+    }
     gpv_comm *cm = new gpv_comm;
     cm->comm = c; cm->device = device; cm->rank = rank; cm->world = world;
     *out = cm;
@@ -1701,7 +1752,16 @@ int gpv_plan_get_sums(gpv_plan *pl, double *sums)
                 if ((spin & 0xFFFFu) == 0 && hipStreamQuery(pl->last_stream) != hipErrorNotReady) break;
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-            if (!seen) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+            if (!seen) {
+                // the stream ended (or failed) without the numbers turning up: the ordinary wait decides, and totals that
+                // still do not carry this evaluation's number are NOT handed out as if they were its result
+                pl->ticket_dirty = true;
+                GPV_HIP(hipStreamSynchronize(pl->last_stream));
+                std::atomic_thread_fence(std::memory_order_acquire);
+                for (int t = 0; t < kNSums; ++t)
+                    if (c[t] != pl->seq) return GPV_ERR_STATE;
+                pl->ticket_dirty = false;
+            }
         } else {
             GPV_HIP(hipStreamSynchronize(pl->last_stream));
         }

@@ -39,6 +39,59 @@ def allreduce_sums(local_sums, group=None):
     return local_sums
 
 
+def _agree_min(flag: int, group=None, device=None) -> int:
+    """MIN of an integer over the ranks of the torch group (on this rank's GPU for backend nccl, on the host otherwise)."""
+    import torch
+    import torch.distributed as dist
+    dev = f"cuda:{device}" if (dist.get_backend(group) == "nccl" and device is not None) else "cpu"
+    t = torch.tensor([int(flag)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
+def negotiate_comm(device, group=None, timeout_s=120.0, log=None):
+    """The library's own RCCL communicator (api.Comm) for this rank, or None — THE SAME ANSWER ON EVERY RANK.
+
+    The ranks first agree that each of them could bind RCCL (gpv_rccl_version() > 0 everywhere), then create the
+    communicator (rank 0's id travels over the torch group; gpv_comm_create is collective and proves itself with a
+    two-double all-reduce), each in a helper thread joined with `timeout_s`, and finally agree that all of them
+    succeeded.  Any failure anywhere => every rank returns None and the caller takes the torch.distributed route
+    (dist.all_reduce on the plan's device buffer).  Without this agreement a rank whose dlopen failed would wait in
+    dist.all_reduce while the others wait inside ncclAllReduce of a communicator it never joined.
+    Returns (comm_or_None, reason)."""
+    import os
+    import threading
+    from .api import Comm
+    say = log or (lambda m: None)
+    forced = os.environ.get("GPV_TORCH_ALLREDUCE", "0") == "1"
+    try:
+        ver = Comm.rccl_version()
+    except Exception as e:                                    # pragma: no cover  (a library without the symbol)
+        ver, _ = 0, say(f"gpv_rccl_version failed: {e!r}")
+    if _agree_min(1 if (ver >= 2000 and not forced) else 0, group, device) == 0:
+        return None, ("GPV_TORCH_ALLREDUCE=1" if forced else f"RCCL not bound on every rank (this rank: version {ver})")
+    box = {}
+
+    def work():
+        try:
+            box["comm"] = Comm.from_torch(device, group)
+        except Exception as e:
+            box["err"] = e
+
+    th = threading.Thread(target=work, name="gpv-comm-create", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    ok = (not th.is_alive()) and "comm" in box
+    if th.is_alive():
+        say(f"gpv_comm_create did not return within {timeout_s:.0f} s")
+    elif "err" in box:
+        say(f"library communicator unavailable: {box['err']!r}")
+    if _agree_min(1 if ok else 0, group, device) == 0:
+        box.pop("comm", None)                                 # (a communicator only some ranks hold is destroyed, not used)
+        return None, "gpv_comm_create failed or timed out on at least one rank"
+    return box["comm"], f"gpv_comm (RCCL {ver})"
+
+
 class ShardedLikelihood:
     """vecchia_likelihood() for cond.yz='z' with the rows split over the ranks of a process group.
 
@@ -49,9 +102,11 @@ class ShardedLikelihood:
     LOCAL_RANK).  The library itself owns an RCCL communicator (api.Comm; its id travels over the torch group once) and
     enqueues the all-reduce of the 8 partial sums and their 64-byte copy to pinned host memory on the evaluation's own
     stream right behind the kernel: torch.distributed is the launcher and the rendezvous, not part of the step.
-    GPV_TORCH_ALLREDUCE=1 selects the older route (dist.all_reduce on the plan's device buffer) instead."""
+    The ranks AGREE on that route first (negotiate_comm); if any of them cannot bind RCCL or create the communicator, or
+    with GPV_TORCH_ALLREDUCE=1, all of them take the older route (dist.all_reduce on the plan's device buffer).
+    `route` says which one runs."""
 
-    def __init__(self, n_rows, z_ord, plan_factory, rank=None, world=None, group=None, device=None):
+    def __init__(self, n_rows, z_ord, plan_factory, rank=None, world=None, group=None, device=None, comm_timeout_s=120.0):
         import torch.distributed as dist
         if rank is None:
             rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -70,15 +125,18 @@ class ShardedLikelihood:
                 raise ValueError(f"rank {rank}: GPU {device} does not exist ({torch.cuda.device_count()} visible)")
             torch.cuda.set_device(device)                  # RCCL reduces on the CURRENT device of each rank
         self.plan = plan_factory(self.row_begin, self.row_end)
+        self.route = "torch.distributed all_reduce (host backend)" if dist.is_initialized() else "none (1 rank)"
         if self._nccl:
             pdev = getattr(self.plan, "device", device)
             if pdev != device:
                 raise ValueError(f"rank {rank}: plan lives on GPU {pdev} but the rank is bound to GPU {device}")
             self.device = device
-            self._native = os.environ.get("GPV_TORCH_ALLREDUCE", "0") != "1" and hasattr(self.plan, "set_comm")
+            # the route is AGREED between the ranks (negotiate_comm): the library's communicator everywhere, or
+            # dist.all_reduce everywhere
+            self._comm, self.route = (None, "plan without set_comm") if not hasattr(self.plan, "set_comm") else \
+                negotiate_comm(device, group, timeout_s=comm_timeout_s)
+            self._native = self._comm is not None
             if self._native:
-                from .api import Comm
-                self._comm = Comm.from_torch(device, group)
                 self.plan.set_comm(self._comm)
             self._stream = torch.cuda.Stream(device=device)
             self._d = torch.zeros(NSUMS, dtype=torch.float64, device=f"cuda:{device}")

@@ -311,6 +311,7 @@ int gpv_mplan_vl_get_one(gpv_mplan *mplan, int replica, double *mean_ord, double
  *   gpv_plan_set_comm(plan, NULL) detaches; detach (or destroy) every plan before gpv_comm_destroy.  Flags with a communicator: GPV_WANT_U | GPV_WANT_LOGLIK_Z |
  *   GPV_WANT_NUMERATOR (the posterior pass does not shard: GPV_ERR_STATE). */
 typedef struct gpv_comm gpv_comm;
+int gpv_rccl_version(void);            /* ncclGetVersion() of the RCCL bound at run time (>= 2000), 0 when none could be bound */
 int gpv_comm_unique_id(void *id128);
 int gpv_comm_create(gpv_comm **comm, int device, int rank, int world, const void *id128);
 int gpv_comm_destroy(gpv_comm *comm);

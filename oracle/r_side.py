@@ -54,6 +54,10 @@ def _lib():
         _LIB.oracle_MaternFun.argtypes = [dp, ctypes.c_long, dp, dp]
         _LIB.oracle_EsqeFun.argtypes = [dp, ctypes.c_long, dp, dp]
         _LIB.oracle_max_threads.restype = ctypes.c_int
+        _LIB.oracle_rows_extended.restype = ctypes.c_long
+        _LIB.oracle_rows_extended.argtypes = [ctypes.c_int, ctypes.c_long, lp, ctypes.c_long, ctypes.c_int, ctypes.c_int,
+                                              dp, lp, dp, dp, ctypes.c_int, dp, dp, dp]
+        _LIB.oracle_long_double_digits.restype = ctypes.c_int
     return _LIB
 
 
@@ -90,6 +94,63 @@ def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_o
     if nf < 0:
         raise ValueError(f"{covType} covariance is not implemented")      # src/U_NZentries.cpp:27-29
     return dict(Lentries=np.array(L), Zentries=Z, n_failed=int(nf))
+
+
+def rows_extended(rows, locs, revNNarray, revCondOnLatent, nuggets, covType, covparms, covVals=None):
+    """The adjudicator: rows `rows` (0-based) of Lentries from the definition of src/U_NZentries.cpp:39-69 evaluated in
+    extended precision — x87 long double through the C restatement (64-bit significand) for the closed-form covariances
+    and the dense variant, 40-digit mpmath for the Bessel branch (src/Matern.cpp:72-84).  Returns (len(rows), p) doubles,
+    exact for the given inputs up to ~cond(S) * 1e-19."""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    locs = np.asfortranarray(locs, dtype=np.float64)
+    Nlocs, d = locs.shape
+    nn = np.asfortranarray(np.nan_to_num(np.asarray(revNNarray, dtype=np.float64), nan=0.0).astype(np.int64))
+    p = nn.shape[1]
+    cond = np.asfortranarray(np.nan_to_num(np.asarray(revCondOnLatent, dtype=np.float64), nan=0.0))
+    nug = np.ascontiguousarray(np.broadcast_to(np.asarray(nuggets, dtype=np.float64), (Nlocs,)))
+    cp = np.ascontiguousarray(covparms, dtype=np.float64)
+    code = {"matern": 0, "esqe": 1}[covType]
+    if covVals is None and code == 0 and float(cp[2]) not in (0.5, 1.5, 2.5):
+        return _rows_extended_mpmath(rows, locs, nn, cond, nug, cp)
+    if _lib().oracle_long_double_digits() < 64:
+        raise RuntimeError("long double is not extended precision on this host")
+    out = np.zeros((rows.size, p))
+    cv = None if covVals is None else np.asfortranarray(covVals, dtype=np.float64)
+    _lib().oracle_rows_extended(max_threads(), rows.size, rows.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), Nlocs, d, p,
+                                _dptr(locs), nn.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), _dptr(cond), _dptr(nug), code,
+                                _dptr(cp), None if cv is None else _dptr(cv), _dptr(out))
+    return out
+
+
+def _rows_extended_mpmath(rows, locs, nn, cond, nug, cp, dps=40):
+    import mpmath as mp
+    Nlocs, p = nn.shape
+    out = np.zeros((len(rows), p))
+    with mp.workdps(dps):
+        sig2, rng, nu = (mp.mpf(float(v)) for v in cp[:3])
+        normcon = sig2 / (mp.mpf(2) ** (nu - 1) * mp.gamma(nu))
+        for r, k in enumerate(rows):
+            inds = nn[k][nn[k] != 0] - 1
+            n0 = len(inds)
+            if n0 == 0:
+                continue
+            S = mp.matrix(n0, n0)
+            for a in range(n0):
+                for b in range(a, n0):
+                    if a == b:
+                        S[a, a] = sig2 + mp.mpf(float(nug[inds[a]])) * (1 - mp.mpf(float(cond[k, p - n0 + a])))
+                        continue
+                    dd = mp.sqrt(sum((mp.mpf(float(locs[inds[a], t])) - mp.mpf(float(locs[inds[b], t]))) ** 2
+                                     for t in range(locs.shape[1])))
+                    s = dd / rng
+                    S[a, b] = S[b, a] = sig2 if dd == 0 else normcon * s ** nu * mp.besselk(nu, s)
+            e = mp.matrix(n0, 1)
+            e[n0 - 1] = 1
+            sol = mp.lu_solve(S, e)
+            if not sol[n0 - 1] > 0:
+                continue
+            out[r, :n0] = [float(v / mp.sqrt(sol[n0 - 1])) for v in sol]
+    return out
 
 
 def U_NZentries_numpy(n, locs, nn, cond, nuggets, nuggets_obsord, covparms):
@@ -696,6 +757,30 @@ def separable_loglik_condz(va, U_entries, z, nuggets):
         s[3] += a * a
         s[4] += zord[k] ** 2 / tau[k]
         s[5] += (d * a - zord[k] / tau[k]) ** 2 / w
+    loglik = -0.5 * (-2 * s[0] + s[1] + s[2] + s[3] + s[4] - s[5] + n * np.log(2 * np.pi))
+    return loglik, s
+
+
+def separable_sums_condz_vectorised(revNN, Lentries, zord, tau):
+    """The sums of separable_loglik_condz for cond.yz == 'z' plans at full size (n = 1e6 in seconds): the same per-row
+    quantities, rows with n0 == p in one vectorised pass, the first rows one by one.  revNN: (n, p) ints, 0 = missing,
+    right-aligned; Lentries: (n, p) left-aligned; tau scalar or (n,).  Returns (loglik, s[6]) like separable_loglik_condz."""
+    revNN = np.asarray(revNN)
+    n, p = revNN.shape
+    L = np.asarray(Lentries)
+    zord = np.asarray(zord, dtype=np.float64)
+    tau = np.broadcast_to(np.asarray(tau, dtype=np.float64), (n,))
+    n0 = (revNN != 0).sum(axis=1)
+    d = L[np.arange(n), n0 - 1]
+    a = np.zeros(n)
+    full = n0 == p
+    a[full] = np.einsum("ij,ij->i", L[full, : p - 1], zord[revNN[full, : p - 1] - 1])
+    for k in np.where(~full)[0]:
+        a[k] = L[k, : n0[k] - 1] @ zord[revNN[k, p - n0[k]: p - 1] - 1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = d * d + 1.0 / tau
+        s = np.array([np.log(d).sum(), np.log(tau).sum(), np.log(w).sum(), (a * a).sum(), (zord ** 2 / tau).sum(),
+                      ((d * a - zord / tau) ** 2 / w).sum()])
     loglik = -0.5 * (-2 * s[0] + s[1] + s[2] + s[3] + s[4] - s[5] + n * np.log(2 * np.pi))
     return loglik, s
 

@@ -29,6 +29,7 @@
  * All matrices at this boundary are COLUMN-MAJOR like the R/Armadillo objects
  * the reference receives (src/RcppExports.cpp:57-63).
  */
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -150,46 +151,55 @@ long oracle_U_NZentries(int Ncores, long n, long Nlocs, int d, int p,
     long nfail = 0;
     memset(Lentries, 0, sizeof(double) * (size_t)Nlocs * (size_t)p);      /* :33 */
 
+    /* scratch per thread, allocated once (round 4: no malloc inside the loop over sets, so that the timed CPU baseline is
+     * the arithmetic and not the allocator) */
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(Ncores) schedule(static) reduction(+ : nfail)   /* :37 */
+#pragma omp parallel num_threads(Ncores) reduction(+ : nfail)                                    /* :37 */
 #endif
-    for (long k = 0; k < Nlocs; ++k) {                                     /* :39 */
-        long inds00[256];
-        double nug[256];
-        int n0 = 0;
-        /* :41-45 — non-zero entries of row k, converted to 0-based */
-        for (int j = 0; j < p; ++j) {
-            long v = revNNarray[k + (long)j * Nlocs];
-            if (v != 0) inds00[n0++] = v - 1;
-        }
-        if (n0 == 0) continue;
-        /* :47 — nug = nuggets[inds00] % (1 - revCond[k, p-n0 .. p-1]) */
-        for (int i = 0; i < n0; ++i) {
-            double c = revCondOnLatent[k + (long)(p - n0 + i) * Nlocs];
-            nug[i] = nuggets[inds00[i]] * (1.0 - c);
-        }
-        double *covmat = (double *)malloc(sizeof(double) * (size_t)n0 * (size_t)n0);
-        double *x = (double *)malloc(sizeof(double) * (size_t)n0);
-        /* :48-55 — full pairwise distance matrix, covariance, + diagmat(nug) */
-        for (int a = 0; a < n0; ++a)
-            for (int b = 0; b < n0; ++b) {
-                double dd = oracle_dist(locs, Nlocs, d, inds00[a], inds00[b]);
-                double c = (covType == ORACLE_COV_MATERN) ? oracle_matern(dd, covparms)
-                                                          : oracle_esqe(dd, covparms);
-                covmat[a * n0 + b] = c + (a == b ? nug[a] : 0.0);
+    {
+        double *covmat = (double *)malloc(sizeof(double) * (size_t)p * (size_t)p);
+        double *x = (double *)malloc(sizeof(double) * (size_t)p);
+        long *inds00 = (long *)malloc(sizeof(long) * (size_t)p);
+        double *nug = (double *)malloc(sizeof(double) * (size_t)p);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (long k = 0; k < Nlocs; ++k) {                                 /* :39 */
+            int n0 = 0;
+            /* :41-45 — non-zero entries of row k, converted to 0-based */
+            for (int j = 0; j < p; ++j) {
+                long v = revNNarray[k + (long)j * Nlocs];
+                if (v != 0) inds00[n0++] = v - 1;
             }
-        /* :57-58 */
-        for (int i = 0; i < n0; ++i) x[i] = 0.0;
-        x[n0 - 1] = 1.0;
-        /* :60-66 */
-        if (oracle_chol_upper(covmat, n0) == 0) {
-            oracle_backsolve_upper(covmat, n0, x);
-            for (int i = 0; i < n0; ++i) Lentries[k + (long)i * Nlocs] = x[i];
-        } else {
-            nfail += 1;
+            if (n0 == 0) continue;
+            /* :47 — nug = nuggets[inds00] % (1 - revCond[k, p-n0 .. p-1]) */
+            for (int i = 0; i < n0; ++i) {
+                double c = revCondOnLatent[k + (long)(p - n0 + i) * Nlocs];
+                nug[i] = nuggets[inds00[i]] * (1.0 - c);
+            }
+            /* :48-55 — full pairwise distance matrix, covariance, + diagmat(nug) */
+            for (int a = 0; a < n0; ++a)
+                for (int b = 0; b < n0; ++b) {
+                    double dd = oracle_dist(locs, Nlocs, d, inds00[a], inds00[b]);
+                    double c = (covType == ORACLE_COV_MATERN) ? oracle_matern(dd, covparms)
+                                                              : oracle_esqe(dd, covparms);
+                    covmat[a * n0 + b] = c + (a == b ? nug[a] : 0.0);
+                }
+            /* :57-58 */
+            for (int i = 0; i < n0; ++i) x[i] = 0.0;
+            x[n0 - 1] = 1.0;
+            /* :60-66 */
+            if (oracle_chol_upper(covmat, n0) == 0) {
+                oracle_backsolve_upper(covmat, n0, x);
+                for (int i = 0; i < n0; ++i) Lentries[k + (long)i * Nlocs] = x[i];
+            } else {
+                nfail += 1;
+            }
         }
         free(covmat);
         free(x);
+        free(inds00);
+        free(nug);
     }
 
     /* :111-115 */
@@ -212,31 +222,37 @@ long oracle_U_NZentries_mat(int Ncores, long n, long Nlocs, int p,
     memset(Lentries, 0, sizeof(double) * (size_t)Nlocs * (size_t)p);
 
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(Ncores) schedule(static) reduction(+ : nfail)   /* :134 */
+#pragma omp parallel num_threads(Ncores) reduction(+ : nfail)                                    /* :134 */
 #endif
-    for (long k = 0; k < Nlocs; ++k) {
-        long inds00[256];
-        int n0 = 0;
-        for (int j = 0; j < p; ++j) {
-            long v = revNNarray[k + (long)j * Nlocs];
-            if (v != 0) inds00[n0++] = v - 1;
-        }
-        if (n0 == 0) continue;
-        double *covmat = (double *)malloc(sizeof(double) * (size_t)n0 * (size_t)n0);
-        double *x = (double *)malloc(sizeof(double) * (size_t)n0);
-        for (int a = 0; a < n0; ++a)
-            for (int b = 0; b < n0; ++b)
-                covmat[a * n0 + b] = covVals[inds00[a] + inds00[b] * Nlocs];   /* :144 */
-        for (int i = 0; i < n0; ++i) x[i] = 0.0;
-        x[n0 - 1] = 1.0;
-        if (oracle_chol_upper(covmat, n0) == 0) {
-            oracle_backsolve_upper(covmat, n0, x);
-            for (int i = 0; i < n0; ++i) Lentries[k + (long)i * Nlocs] = x[i];
-        } else {
-            nfail += 1;
+    {
+        double *covmat = (double *)malloc(sizeof(double) * (size_t)p * (size_t)p);
+        double *x = (double *)malloc(sizeof(double) * (size_t)p);
+        long *inds00 = (long *)malloc(sizeof(long) * (size_t)p);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+        for (long k = 0; k < Nlocs; ++k) {
+            int n0 = 0;
+            for (int j = 0; j < p; ++j) {
+                long v = revNNarray[k + (long)j * Nlocs];
+                if (v != 0) inds00[n0++] = v - 1;
+            }
+            if (n0 == 0) continue;
+            for (int a = 0; a < n0; ++a)
+                for (int b = 0; b < n0; ++b)
+                    covmat[a * n0 + b] = covVals[inds00[a] + inds00[b] * Nlocs];   /* :144 */
+            for (int i = 0; i < n0; ++i) x[i] = 0.0;
+            x[n0 - 1] = 1.0;
+            if (oracle_chol_upper(covmat, n0) == 0) {
+                oracle_backsolve_upper(covmat, n0, x);
+                for (int i = 0; i < n0; ++i) Lentries[k + (long)i * Nlocs] = x[i];
+            } else {
+                nfail += 1;
+            }
         }
         free(covmat);
         free(x);
+        free(inds00);
     }
     for (long i = 0; i < n; ++i) {
         Zentries[2 * i] = (-1) / sqrt(nuggets_obsord[i]);
@@ -244,6 +260,107 @@ long oracle_U_NZentries_mat(int Ncores, long n, long Nlocs, int p,
     }
     return nfail;
 }
+
+/*
+ * EXTENDED-PRECISION ADJUDICATOR (round 4).  The same per-set definition (src/U_NZentries.cpp:39-69 with the covariance of
+ * src/Matern.cpp:24-71 / src/Esqe.cpp:17-39) evaluated in x87 `long double` (64-bit significand, eps = 5.4e-20) for a LIST of
+ * rows: the exact answer for the given double inputs up to cond(S) * 1e-19.  Where the HIP path and the double oracle above
+ * disagree by more than the flat 1e-8 (ill-conditioned blocks: two correct fp64 factorisations differ by ~cond * eps), the
+ * tests measure each of them against this.  Constants sqrt(3), sqrt(5) are the exact irrationals here, not their double
+ * roundings: the reference's `sqrt(3)` is a double, so its own rounding error (1e-16 relative in the argument of exp) counts
+ * as part of the double implementations' error, as it should.
+ *   rows[nrows]  0-based row numbers;  out: nrows x p ROW-major, left-aligned like Lentries;  covVals != NULL: the dense
+ *   variant (src/U_NZentries.cpp:144), locs / nuggets / revCond unused.
+ * returns the number of rows with a non-positive pivot.
+ */
+static long double oracle_cov_ld(long double dist, int covType, const double *cp)
+{
+    if (covType == ORACLE_COV_ESQE) {
+        if (dist == 0) return (long double)cp[0] + (long double)cp[2];
+        long double s1 = dist / (long double)cp[1], s2 = dist / (long double)cp[3];
+        return (long double)cp[0] * expl(-s1) + (long double)cp[2] * expl(-s2 * s2);
+    }
+    if (dist == 0) return (long double)cp[0];
+    long double s = dist / (long double)cp[1];
+    if (cp[2] == 0.5) return (long double)cp[0] * expl(-s);
+    if (cp[2] == 1.5) { long double t = sqrtl(3.0L) * s; return (long double)cp[0] * (1 + t) * expl(-t); }
+    if (cp[2] == 2.5) { long double t = sqrtl(5.0L) * s; return (long double)cp[0] * expl(-t) * (1 + t + t * t / 3); }
+    return (long double)NAN;
+}
+
+long oracle_rows_extended(int Ncores, long nrows, const long *rows, long Nlocs, int d, int p,
+                          const double *locs, const long *revNNarray, const double *revCondOnLatent,
+                          const double *nuggets, int covType, const double *covparms, const double *covVals,
+                          double *out)
+{
+    long nfail = 0;
+    memset(out, 0, sizeof(double) * (size_t)nrows * (size_t)p);
+#ifdef _OPENMP
+#pragma omp parallel num_threads(Ncores) reduction(+ : nfail)
+#endif
+    {
+        long double *a = (long double *)malloc(sizeof(long double) * (size_t)p * (size_t)p);
+        long double *x = (long double *)malloc(sizeof(long double) * (size_t)p);
+        long *inds00 = (long *)malloc(sizeof(long) * (size_t)p);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (long r = 0; r < nrows; ++r) {
+            long k = rows[r];
+            int n0 = 0;
+            for (int j = 0; j < p; ++j) {
+                long v = revNNarray[k + (long)j * Nlocs];
+                if (v != 0) inds00[n0++] = v - 1;
+            }
+            if (n0 == 0) continue;
+            for (int i = 0; i < n0; ++i)
+                for (int j = 0; j < n0; ++j) {
+                    long double c;
+                    if (covVals) {
+                        c = covVals[inds00[i] + inds00[j] * Nlocs];
+                    } else {
+                        long double ssq = 0;
+                        for (int t = 0; t < d; ++t) {
+                            long double df = (long double)locs[inds00[i] + (long)t * Nlocs] - (long double)locs[inds00[j] + (long)t * Nlocs];
+                            ssq += df * df;
+                        }
+                        c = oracle_cov_ld(sqrtl(ssq), covType, covparms);
+                        if (i == j)
+                            c += (long double)nuggets[inds00[i]] * (1.0L - (long double)revCondOnLatent[k + (long)(p - n0 + i) * Nlocs]);
+                    }
+                    a[i * n0 + j] = c;
+                }
+            /* upper Cholesky + back substitution for e_last, all in long double */
+            int bad = 0;
+            for (int j = 0; j < n0 && !bad; ++j) {
+                long double ajj = a[j * n0 + j];
+                for (int q = 0; q < j; ++q) ajj -= a[q * n0 + j] * a[q * n0 + j];
+                if (!(ajj > 0)) { bad = 1; break; }
+                ajj = sqrtl(ajj);
+                a[j * n0 + j] = ajj;
+                for (int c = j + 1; c < n0; ++c) {
+                    long double s = a[j * n0 + c];
+                    for (int q = 0; q < j; ++q) s -= a[q * n0 + j] * a[q * n0 + c];
+                    a[j * n0 + c] = s / ajj;
+                }
+            }
+            if (bad) { nfail += 1; continue; }
+            for (int i = 0; i < n0; ++i) x[i] = 0;
+            x[n0 - 1] = 1;
+            for (int j = n0 - 1; j >= 0; --j) {
+                x[j] /= a[j * n0 + j];
+                for (int i = j - 1; i >= 0; --i) x[i] -= x[j] * a[i * n0 + j];
+            }
+            for (int i = 0; i < n0; ++i) out[r * (long)p + i] = (double)x[i];
+        }
+        free(a);
+        free(x);
+        free(inds00);
+    }
+    return nfail;
+}
+
+int oracle_long_double_digits(void) { return LDBL_MANT_DIG; }
 
 int oracle_max_threads(void)
 {

@@ -94,3 +94,41 @@ def test_shard_rows_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_rows(10, 2, 2)
+
+
+def _negotiate_worker(rank, world, port, q, force_rank):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if rank == force_rank:
+        os.environ["GPV_TORCH_ALLREDUCE"] = "1"                    # ONE rank cannot (will not) use the library's communicator
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gpvecchia_amd.distributed import negotiate_comm
+        msgs = []
+        comm, why = negotiate_comm(0, None, timeout_s=30, log=msgs.append)
+        q.put((rank, comm is None, why, msgs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("force_rank", [1, -1])
+def test_ranks_agree_on_the_collective_route_world2_gloo(force_rank):
+    """negotiate_comm returns the same answer on every rank and never leaves one rank inside a collective the other does
+    not enter: with one rank opting out (force_rank = 1) both fall back; with none opting out on this GPU-less box
+    gpv_comm_create fails on both (no device) and both fall back as well — in both cases within seconds, no hang."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_negotiate_worker, args=(r, 2, port, q, force_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    import torch
+    if torch.cuda.device_count() == 0 or force_rank >= 0:
+        assert res[0][1] and res[1][1], res                          # both None
+    assert res[0][1] == res[1][1]                                    # the same route on both ranks, whatever it is

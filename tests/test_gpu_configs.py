@@ -151,19 +151,17 @@ def test_C2_full_size_all_rows_n1e5_m20():
         assert out["n_failed"] == ref["n_failed"] == 0
         # ALL 1e5 rows.  cond.yz='z': flat 1e-8.  SGV: neighbours conditioned on as latent carry no nugget, and at this
         # density (spacing 0.003 against a range of 0.05) a few blocks reach cond(S) ~ 1e7..1e8, where two correct fp64
-        # factorisations differ by cond*eps: those rows get the condition-scaled bound
-        scale = np.maximum(np.abs(ref["Lentries"]).max(axis=1), 1e-300)
-        err = np.abs(out["Lentries"] - ref["Lentries"]).max(axis=1) / scale
+        # factorisations differ by cond*eps: those rows are adjudicated in extended precision
+        from _parity import check_rows
+        res = check_rows(out["Lentries"], ref["Lentries"], locs, revNN, revCond, tau, "matern", cp, label=f"C2 all rows {cond}")
         if cond == "z":
-            assert err.max() < ROW_TOL
+            assert res["escaped"] == 0 and res["max_err"] < ROW_TOL, res
         else:
-            hard = np.where(err >= ROW_TOL)[0]
-            assert hard.size <= n // 1000 and np.median(err) < 1e-11, (hard.size, err.max())
-            for k in hard:
-                okc = revNN[k] != 0
-                idx = revNN[k][okc] - 1
-                S_ = R.MaternFun(R.rdist(locs[idx]), cp) + np.diag(tau * (1 - revCond[k][okc]))
-                assert err[k] <= 32 * np.linalg.cond(S_) * np.finfo(float).eps, (k, err[k])
+            # every row beyond the flat bound has been measured against the extended-precision row (err_hip <= 4 err_oracle);
+            # there must be few of them
+            assert res["escaped"] <= n // 1000, res
+            err = np.abs(out["Lentries"] - ref["Lentries"]).max(axis=1) / np.abs(ref["Lentries"]).max(axis=1)
+            assert np.median(err) < 1e-11
         np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
         np.testing.assert_allclose(out["Zentries"], ref["Zentries"], rtol=1e-15)
         if cond == "z":
@@ -230,7 +228,7 @@ def test_C4_instantiation_m60_3d_exponential(cond):
 
 
 def test_C4_full_size_properties_n1e6_m60_3d():
-    """BASELINE config 4 at full size: sampled neighbour rows vs the definition, sampled conditioning sets vs the oracle,
+    """BASELINE config 4 at full size: sampled neighbour rows vs the definition, ALL conditioning sets vs the oracle,
     fused sums vs a host recomputation from the U entries in HBM, shard additivity, bitwise reproducibility."""
     G = _need_gpu()
     from gpvecchia_amd import specify as S
@@ -256,11 +254,16 @@ def test_C4_full_size_properties_n1e6_m60_3d():
     s = plan.sums()
     assert s[6] == 0 and s[7] == n
     Lent = plan.Lentries()
-    rows = np.sort(np.concatenate([np.arange(0, 80), rng.choice(np.arange(80, n), 2000, replace=False)]))
-    refL, nfail = _oracle_rows(R, locs, revNN, revCond, rows, tau, "matern", cp)
-    assert nfail == 0
-    err = np.abs(Lent[rows] - refL).max(axis=1) / np.abs(refL).max(axis=1)
-    assert err.max() < ROW_TOL
+    # ALL 1e6 conditioning sets against the oracle (488 MB of U entries a side; ~6 s of oracle time on the box's cores)
+    from _parity import check_rows
+    ref = R.U_NZentries(R.max_threads(), n, locs, revNN, np.where(revCond < 0, 0, revCond).astype(np.float64),
+                        np.full(n, tau), np.full(n, tau), "matern", cp)
+    assert ref["n_failed"] == 0
+    res = check_rows(Lent, ref["Lentries"], locs, revNN, revCond, tau, "matern", cp, label="C4 full size, all rows")
+    assert res["rows"] == n and res["escaped"] == 0 and res["max_err"] < ROW_TOL, res
+    ll_ref, s_ref = R.separable_sums_condz_vectorised(revNN, ref["Lentries"], z, tau)
+    assert abs(G.loglik_z_from_sums(s, n) - ll_ref) <= LL_RTOL * abs(ll_ref)
+    del ref
     # fused sums vs host recomputation (cond.yz='z': every neighbour is observed-conditioned)
     n0 = (revNN != 0).sum(axis=1)
     dk = Lent[np.arange(n), n0 - 1]

@@ -3,6 +3,8 @@ permlane instructions whose hazards hipcc cannot see, so beyond the fixed parity
 combinations of row length, dimension, covariance family, conditioning mode and nugget layout against the oracle and
 (b) replays the same launch many times at sizes that fill the chip, asserting bit-identical outputs (a missed wait state
 shows up as a rare, placement-dependent difference)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -19,6 +21,10 @@ def _need_gpu():
 # 62, 76, 86: one-dimensional exponential covariances (found by a 200-seed sweep): a Markov process, the weights of all
 # but the adjacent neighbours are exactly zero in exact arithmetic, and the oracle's elimination order happens to return
 # 0.0 where another order returns 1e-17 of the row's largest entry
+# rows per seed that miss the flat 1e-8 against the oracle and pass the extended-precision adjudication (tests/_parity.py)
+ESCAPES = {}
+
+
 @pytest.mark.parametrize("seed", list(range(24)) + [62, 76, 86])
 def test_random_shapes_against_oracle(seed):
     G = _need_gpu()
@@ -56,15 +62,11 @@ def test_random_shapes_against_oracle(seed):
     differs = (L1 == 0) != (L0 == 0)
     assert not np.any(differs & (np.maximum(np.abs(L0), np.abs(L1)) > 1e-13 * rowmax))
     np.testing.assert_array_equal((L1 == 0).all(axis=1), (L0 == 0).all(axis=1))          # failed rows stay all-zero
-    covfun = R.EsqeFun if covmodel == "esqe" else R.MaternFun
-    eps = np.finfo(float).eps
-    for k in range(n):
-        err = np.abs(L1[k] - L0[k]).max() / max(np.abs(L0[k]).max(), 1e-300)
-        if err > 1e-10:
-            ok = ~np.isnan(prep["revNNarray"][k])
-            idx = prep["revNNarray"][k][ok].astype(int) - 1
-            S = covfun(R.rdist(locs[idx]), cp) + np.diag(tau[idx] * (1 - prep["revCond"][k][ok]))
-            assert err <= 32 * np.linalg.cond(S) * eps, (seed, m, d, cond, covmodel, k, err)
+    from _parity import check_rows
+    res = check_rows(L1, L0, locs, prep["revNNarray"], prep["revCond"], tau, covmodel, cp,
+                     label=f"fuzz seed {seed} m={m} d={d} {cond} {covmodel}")
+    if not os.environ.get("GPV_PARITY_SURVEY"):
+        assert res["escaped"] <= ESCAPES.get(seed, 0), res
     np.testing.assert_allclose(out["Zentries"], ref["U_entries"]["Zentries"], rtol=1e-15)
     if ref["U_entries"]["n_failed"] == 0:
         prod = dict(va)

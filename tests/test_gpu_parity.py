@@ -29,29 +29,16 @@ def _row_err(A, B):
     return (np.abs(A - B).max(axis=1) / scale).max()
 
 
-def _assert_rows_close(out, ref, va, cp, tau, covfun=None):
-    """Per-row normwise bound scaled by the block's condition number:
-    err_k <= max(1e-10, 32 * cond(S_k) * eps).  This is <= 1e-8 (the north-star tolerance) for every
-    block with cond <= 1.4e6 and is the best ANY fp64 factorisation can promise beyond that
-    (two correct implementations differ by ~cond*eps)."""
-    from oracle import r_side as R
-    covfun = covfun or R.MaternFun
+def _assert_rows_close(out, ref, va, cp, tau, covmodel="matern", max_escaped=0):
+    """Every row within the flat 1e-8 of the oracle's (normwise); a row beyond it is adjudicated against the same
+    definition in extended precision (tests/_parity.py: err_hip <= max(4 err_oracle, 1e-8)) and COUNTED: the caller
+    states how many such rows its case may have."""
+    from _parity import check_rows
     prep = va["U_prep"]
-    locs = va["locsord"]
-    eps = np.finfo(float).eps
-    worst = 0.0
-    for k in range(locs.shape[0]):
-        ok = ~np.isnan(prep["revNNarray"][k])
-        idx = prep["revNNarray"][k][ok].astype(int) - 1
-        a, b = out[k], ref[k]
-        err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
-        if err <= 1e-10:
-            continue
-        S = covfun(R.rdist(locs[idx]), cp) + np.diag(tau * (1 - prep["revCond"][k][ok]))
-        tol = max(1e-10, 32 * np.linalg.cond(S) * eps)
-        assert err <= tol, (k, err, tol)
-        worst = max(worst, err)
-    return worst
+    res = check_rows(out, ref, va["locsord"], prep["revNNarray"], prep["revCond"], tau, covmodel, cp)
+    if not os.environ.get("GPV_PARITY_SURVEY"):           # survey run: log the counts (GPV_PARITY_LOG), keep going
+        assert res["escaped"] <= max_escaped, res
+    return res
 
 
 def _case(n, m, d, seed, cond, ordering="none"):
@@ -1086,7 +1073,7 @@ def test_zero_nuggets_surgery():
 def test_full_size_properties_n1e6_m30():
     """BASELINE.json's full size (n = 1e6, m = 30, 2-D, Matern 1.5): size-independent properties.
       * neighbour arrays: a random sample of rows equals the brute-force definition bit for bit;
-      * U entries: a random sample of conditioning sets equals the oracle (sub-problem with remapped indices);
+      * U entries: ALL 1e6 conditioning sets against the oracle, flat 1e-8; log-likelihood against the oracle's;
       * the fused likelihood sums equal the same sums recomputed on the host from the U entries left in HBM;
       * additivity: shard sums add up to the unsharded sums; evaluation is bitwise reproducible."""
     G = _need_gpu()
@@ -1112,20 +1099,20 @@ def test_full_size_properties_n1e6_m30():
     s = plan.sums()
     assert s[6] == 0 and s[7] == n
     Lent = plan.Lentries()
-    # -- sampled conditioning sets against the oracle
-    rows = np.sort(np.concatenate([np.arange(0, 40), rng.choice(np.arange(40, n), 3000, replace=False)]))
-    sub = revNN[rows]
-    used = np.unique(sub[sub != 0]) - 1
-    remap = np.zeros(n + 1, dtype=np.int64)
-    remap[used + 1] = np.arange(1, used.size + 1)
-    Nl = max(used.size, len(rows))
-    nnp = np.zeros((Nl, p), dtype=np.int64); nnp[: len(rows)] = remap[sub]
-    cdp = np.zeros((Nl, p)); cdp[: len(rows)] = np.where(revCond[rows] < 0, 0, revCond[rows])
-    lp = np.zeros((Nl, 2)); lp[: used.size] = locs[used]
-    ref = R.U_NZentries(R.max_threads(), 1, lp, nnp, cdp, np.full(Nl, tau), np.full(1, tau), "matern", cp)
-    refL = ref["Lentries"][: len(rows)]
-    err = np.abs(Lent[rows] - refL).max(axis=1) / np.abs(refL).max(axis=1)
-    assert err.max() < ROW_TOL
+    # -- ALL 1e6 conditioning sets against the oracle (its C restatement takes seconds on the box's host cores): flat 1e-8,
+    #    no row may need the extended-precision adjudication (cond.yz='z': every block carries the nugget)
+    from _parity import check_rows
+    ref = R.U_NZentries(R.max_threads(), n, locs, revNN, np.where(revCond < 0, 0, revCond).astype(np.float64),
+                        np.full(n, tau), np.full(n, tau), "matern", cp)
+    assert ref["n_failed"] == 0
+    res = check_rows(Lent, ref["Lentries"], locs, revNN, revCond, tau, "matern", cp, label="C3 full size, all rows")
+    assert res["rows"] == n and res["escaped"] == 0 and res["max_err"] < ROW_TOL, res
+    np.testing.assert_array_equal(Lent == 0, ref["Lentries"] == 0)
+    ll_ref, s_ref = R.separable_sums_condz_vectorised(revNN, ref["Lentries"], z, tau)
+    assert abs(G.loglik_z_from_sums(s, n) - ll_ref) <= LL_RTOL * abs(ll_ref)
+    np.testing.assert_allclose(s[0], s_ref[0], rtol=1e-11)
+    np.testing.assert_allclose(s[1], s_ref[3], rtol=1e-10)
+    del ref
     # -- fused sums vs host recomputation from the U entries (cond.yz='z': every neighbour is observed-conditioned)
     n0 = (revNN != 0).sum(axis=1)
     dk = Lent[np.arange(n), n0 - 1]
@@ -1191,7 +1178,11 @@ def test_ill_conditioned_rows_normwise():
     out = G.U_NZentries(1, n, va["locsord"], prep["revNNarray"], prep["revCond"], np.full(n, .1), np.full(n, .1),
                         "matern", cp)
     assert out["n_failed"] == ref["n_failed"]
-    _assert_rows_close(out["Lentries"], ref["Lentries"], va, cp, 0.1)
+    # cond(S) ~ 1e8 on most rows: EVERY row beyond the flat 1e-8 is measured against the extended-precision row (long
+    # double), not one sample: the Gauss-Jordan sweep has a different error path than dpotrf + dtrtrs
+    res = _assert_rows_close(out["Lentries"], ref["Lentries"], va, cp, 0.1, max_escaped=n)
+    assert res["escaped"] >= 1            # the case is there to exercise the adjudication
+    # and one of them against 40-digit mpmath, to pin the long-double adjudicator itself
     import mpmath as mp
     mp.mp.dps = 40
     k = n - 1
@@ -1205,9 +1196,11 @@ def test_ill_conditioned_rows_normwise():
     e = mp.matrix(m + 1, 1); e[m] = 1
     sol = mp.lu_solve(S, e)
     x = np.array([float(v / mp.sqrt(sol[m])) for v in sol])
+    xl = R.rows_extended([k], va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)[0]
+    assert np.abs(xl - x).max() <= 1e-11 * np.abs(x).max()
     err_gpu = np.abs(out["Lentries"][k] - x).max() / np.abs(x).max()
     err_ref = np.abs(ref["Lentries"][k] - x).max() / np.abs(x).max()
-    assert err_gpu < max(10 * err_ref, 1e-9)
+    assert err_gpu <= max(4 * err_ref, 1e-8)
 
 
 # ---------------------------------------------------------------------------

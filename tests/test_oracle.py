@@ -5,6 +5,7 @@ are asserted here:
   * tests/testthat/test-MaternFun.r:5-41 — closed forms of MaternFun
   * vignettes/GPvecchia_vignette.Rmd:129-139 — m = n-1 reproduces dmvnorm
 plus LAPACK (scipy dpotrf/dtrtrs = what arma::chol/solve call) and mpmath."""
+import os
 import numpy as np
 import pytest
 
@@ -233,3 +234,103 @@ def test_whichCondOnLatent_properties():
     assert np.all(C[:, 0] == 1)
     assert np.array_equal(np.isnan(C), np.isnan(NN))
     assert set(np.unique(C[~np.isnan(C)])) <= {0.0, 1.0}
+
+
+# ---------------------------------------------------------------------------
+# round 4: the extended-precision adjudicator and the vectorised closed-form sums
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("covType,cp", [("matern", [1.2, 0.3, 0.5]), ("matern", [1.2, 0.3, 1.5]), ("matern", [1.2, 0.3, 2.5]),
+                                        ("esqe", [1.0, 0.3, 0.5, 0.2])])
+def test_extended_precision_rows_agree_with_mpmath_and_bracket_the_double_oracle(covType, cp):
+    """rows_extended (x87 long double) is the adjudicator of tests/_parity.py: it must agree with a 40-digit mpmath
+    evaluation of the same definition to ~cond * 1e-19 — far below the double oracle's own error on the same rows."""
+    import mpmath as mp
+    locs, va = _random_case(120, 10, 2, 21, cond="y")               # all-latent conditioning: no nugget inside the blocks
+    prep = va["U_prep"]
+    rows = np.array([0, 1, 7, 60, 119])
+    ex = R.rows_extended(rows, va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, covType, cp)
+    ref = R.createU(va, cp, 0.1, covType)["U_entries"]["Lentries"]
+    nn = prep["revNNarray"]
+    with mp.workdps(40):
+        for r, k in enumerate(rows):
+            idx = nn[k][~np.isnan(nn[k])].astype(int) - 1
+            n0 = len(idx)
+            S = mp.matrix(n0, n0)
+            for a in range(n0):
+                for b in range(n0):
+                    dd = mp.sqrt(sum((mp.mpf(float(va["locsord"][idx[a], t])) - mp.mpf(float(va["locsord"][idx[b], t]))) ** 2
+                                     for t in range(2)))
+                    if covType == "esqe":
+                        S[a, b] = (mp.mpf(cp[0]) + mp.mpf(cp[2]) if dd == 0 else
+                                   mp.mpf(cp[0]) * mp.exp(-dd / mp.mpf(cp[1])) + mp.mpf(cp[2]) * mp.exp(-(dd / mp.mpf(cp[3])) ** 2))
+                    else:
+                        s = dd / mp.mpf(cp[1])
+                        nu = cp[2]
+                        S[a, b] = (mp.mpf(cp[0]) if dd == 0 else
+                                   mp.mpf(cp[0]) * mp.exp(-s) if nu == 0.5 else
+                                   mp.mpf(cp[0]) * (1 + mp.sqrt(3) * s) * mp.exp(-mp.sqrt(3) * s) if nu == 1.5 else
+                                   mp.mpf(cp[0]) * mp.exp(-s * mp.sqrt(5)) * (1 + mp.sqrt(5) * s + 5 * s * s / 3))
+            e = mp.matrix(n0, 1); e[n0 - 1] = 1
+            sol = mp.lu_solve(S, e)
+            x = np.array([float(v / mp.sqrt(sol[n0 - 1])) for v in sol])
+            sc = np.abs(x).max()
+            err_ld = np.abs(ex[r, :n0] - x).max() / sc
+            err_dbl = np.abs(ref[k, :n0] - x).max() / sc
+            condS = np.linalg.cond(np.array(S.tolist(), dtype=float))
+            assert err_ld <= max(2e-16, 1e-18 * condS), (k, err_ld, condS)       # rounding of the result to double + cond * eps_ld
+            assert err_dbl <= 64 * condS * np.finfo(float).eps, (k, err_dbl, condS)
+            assert np.all(ex[r, n0:] == 0)
+
+
+def test_extended_precision_rows_general_nu_and_dense_variant():
+    locs, va = _random_case(60, 6, 2, 5, cond="SGV")
+    prep = va["U_prep"]
+    cp = [1.0, 0.25, 1.1]                                             # Bessel branch: mpmath inside rows_extended
+    rows = np.array([0, 3, 30, 59])
+    ex = R.rows_extended(rows, va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)
+    ref = R.createU(va, cp, 0.1)["U_entries"]["Lentries"]
+    assert np.abs(ex - ref[rows]).max() <= 1e-9 * np.abs(ref[rows]).max()
+    K = R.MaternFun(R.rdist(va["locsord"]), [1.0, 0.25, 0.5])         # dense variant (src/U_NZentries.cpp:144): no nugget
+    exm = R.rows_extended(np.arange(60), va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp, covVals=K)
+    refm = R.createU(va, cp, 0.1, covmodel=K)["U_entries"]["Lentries"]
+    assert np.abs(exm - refm).max() <= 1e-11 * np.abs(refm).max()
+
+
+def test_vectorised_separable_sums_equal_the_row_loop():
+    locs, va = _random_case(300, 9, 2, 13, cond="z")
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal(300)
+    cp = [1.1, 0.2, 1.5]
+    for tau in (0.1, 0.05 + rng.random(300)):
+        ref = R.createU(va, cp, tau)["U_entries"]
+        l1, s1 = R.separable_loglik_condz(va, ref, z, tau)
+        nn = np.nan_to_num(va["U_prep"]["revNNarray"]).astype(int)
+        zord = z[va["ord_z"] - 1]
+        tord = tau if np.ndim(tau) == 0 else tau[va["ord_z"] - 1]
+        l2, s2 = R.separable_sums_condz_vectorised(nn, ref["Lentries"], zord, tord)
+        assert abs(l1 - l2) <= 1e-13 * abs(l1)
+        np.testing.assert_allclose(s2, s1, rtol=1e-12)
+
+
+def test_check_rows_adjudicates_against_extended_precision():
+    """tests/_parity.py: a row off by more than 1e-8 passes only if it is as close to the extended-precision row as the
+    oracle's own row (factor 4); a wrong row fails."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _parity import check_rows
+    locs, va = _random_case(80, 8, 2, 2, cond="y")
+    prep = va["U_prep"]
+    cp = [1.0, 0.3, 1.5]
+    ref = R.createU(va, cp, 0.1)["U_entries"]["Lentries"]
+    res = check_rows(ref.copy(), ref, va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)
+    assert res["escaped"] == 0 and res["rows"] == 80
+    bad = ref.copy()
+    bad[40, 2] *= 1 + 1e-6
+    with pytest.raises(AssertionError):
+        check_rows(bad, ref, va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)
+    # a "reference" that is itself off: the other side, being exact to 1e-19 * cond, passes the adjudication and is counted
+    ex = R.rows_extended(np.arange(80), va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)
+    off = ref.copy()
+    off[40, 2] *= 1 + 1e-6
+    res = check_rows(ex, off, va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)
+    assert res["escaped"] == 1

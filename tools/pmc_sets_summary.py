@@ -1,4 +1,4 @@
-"""Developer tool: print the counters of the LAST gpv_sets_kernel dispatch of each PMC pass written by tools/pmc_r01.sh."""
+"""Developer tool: print the counters of the LAST gpv_sets_kernel dispatch of each PMC pass written by tools/sessions/pmc_r01.sh."""
 import csv
 import glob
 import sys
