@@ -696,7 +696,25 @@ def main():
                                      "sets_kernel_ms": km, "loglik": ll, "levels": nlev, "setup_s": round(ts, 2),
                                      "what": "the reference's defaults: ordering='maxmin', cond.yz='SGV'; set kernel + "
                                              "posterior pass (U2V) on one GPU; does not shard"}
-                    del ps, va
+                    del ps
+                    # mode L on the reference's DEFAULT ordering ("ordering='none' ... unless the maxmin builder
+                    # exists"): maxmin with the cut-9 quirk (R/vecchia_specify.R:103-106), cond.yz='z', same locations / m / covparms
+                    try:
+                        rn = va["U_prep"]["revNNarray"]
+                        rc = np.where(rn != 0, 0, -1).astype(np.int8)       # cond.yz='z' (R/vecchia_specify.R:189-190)
+                        rc[:, -1] = 1
+                        pm = G.Plan(va["locsord"], rn, rc, device=local_rank)
+                        pm.set_data(z[va["ord_z"] - 1])
+                        el, km, ll = measure(pm, G.GPV_WANT_LOGLIK_Z, False, args.steps, 2)
+                        tfm = flops_per_set(p, d) * n / (km * 1e-3) / 1e12
+                        sec["mode_L_maxmin"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
+                                                "kernel_ms": km, "fp64_frac": tfm / FP64_PEAK_TF, "loglik": ll,
+                                                "what": "mode L (fused log-likelihood, cond.yz='z') on ordering='maxmin' (the reference's "
+                                                        "default ordering incl. its cut-9 quirk) instead of the headline's ordering='none'"}
+                        del pm
+                    except Exception as e:
+                        sec["mode_L_maxmin"] = {"error": repr(e)}
+                    del va
                 except Exception as e:                       # never lose the headline line to a secondary failure
                     sec["mode_S"] = {"error": repr(e)}
             if args.config == "C3" and not custom:

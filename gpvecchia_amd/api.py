@@ -172,9 +172,10 @@ class Comm:
         raw = exchange((bytes(ident.raw) if st0 == 0 else b"") if rank == 0 else None)
         if rank == 0:
             L.check(st0, "gpv_comm_unique_id")
+        if raw == b"":
+            raise RuntimeError("Comm: rank 0 could not produce the communicator id (no RCCL to bind?)")
         if not isinstance(raw, (bytes, bytearray)) or len(raw) != 128:
-            raise RuntimeError("Comm: rank 0 could not produce the communicator id (no RCCL to bind?)" if raw == b"" else
-                               "Comm: the exchange must hand every rank the 128 bytes of rank 0")
+            raise ValueError("Comm: the exchange must hand every rank the 128 bytes of rank 0")
         ident = C.create_string_buffer(bytes(raw), 128)
         self._h = C.c_void_p()
         self.device, self.rank, self.world = int(device), int(rank), int(world)

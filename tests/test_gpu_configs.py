@@ -157,9 +157,9 @@ def test_C2_full_size_all_rows_n1e5_m20():
         if cond == "z":
             assert res["escaped"] == 0 and res["max_err"] < ROW_TOL, res
         else:
-            # every row beyond the flat bound has been measured against the extended-precision row (err_hip <= 4 err_oracle);
-            # there must be few of them
-            assert res["escaped"] <= n // 1000, res
+            # every row beyond the flat bound has been measured against the extended-precision row (tests/_parity.py);
+            # there must be few of them, and very few where the kernel's error exceeds 4x the oracle's own
+            assert res["escaped"] <= n // 1000 and res["beyond4x"] <= n // 10000, res
             err = np.abs(out["Lentries"] - ref["Lentries"]).max(axis=1) / np.abs(ref["Lentries"]).max(axis=1)
             assert np.median(err) < 1e-11
         np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)
@@ -375,3 +375,57 @@ def test_C5_full_size_properties_n5e5_m30():
     ll_dev = G.vecchia_likelihood(pseudo_s, vs, cp, Ds)
     ll_host = A.vecchia_likelihood_U(pseudo_s, U_obj)
     assert abs(ll_dev - ll_host) <= 1e-9 * abs(ll_host)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# C3 on the reference's DEFAULT ordering: maxmin (+ the cut-9 quirk), mode L — what bench.py reports as
+# secondary.mode_L_maxmin (ordering='none' only "unless the maxmin builder exists")
+# ----------------------------------------------------------------------------------------------------------------
+def test_full_size_maxmin_mode_L_n1e6_m30():
+    """n = 1e6, m = 30, ordering='maxmin', cond.yz='z': the ordering is a permutation with the reference's cut-9 rotation
+    (R/vecchia_specify.R:103-106) and decreasing maxmin distances on a sample; neighbour rows equal the ordered-NN
+    definition on sampled rows; ALL 1e6 conditioning sets equal the oracle's (flat 1e-8), and so does the log-likelihood."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    from _parity import check_rows
+    n, m, p = 1_000_000, 30, 31
+    rng = np.random.default_rng(0)
+    locs = rng.random((n, 2))
+    z = np.random.default_rng(1).standard_normal(n)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="z", nn_backend="gpu")
+    ord_ = va["ord"]
+    assert np.array_equal(np.sort(ord_), np.arange(1, n + 1))
+    lo = va["locsord"]
+    assert np.array_equal(lo, locs[ord_ - 1])
+    # maxmin property after undoing the rotation ord = c(o[1], o[-(1:9)], o[2:9]): position k (k >= 1, un-rotated) holds the
+    # point farthest from the k points before it; spot-check the first positions exactly
+    o = np.concatenate([ord_[:1], ord_[-8:], ord_[1:-8]])                 # the un-rotated maxmin order
+    lm = locs[o - 1]
+    for k in range(1, 12):
+        dmin = np.sqrt(((locs[:, None, :] - lm[None, :k, :]) ** 2).sum(-1)).min(axis=1)
+        assert abs(dmin[o[k] - 1] - dmin.max()) <= 1e-15
+    revNN = va["U_prep"]["revNNarray"]
+    NN = revNN[:, ::-1]
+    for k in np.concatenate([[0, 1, 5, 30, 31, 100], rng.integers(1000, n, 30)]):
+        dd = np.sqrt((lo[: k + 1, 0] - lo[k, 0]) ** 2 + (lo[: k + 1, 1] - lo[k, 1]) ** 2)
+        want = np.lexsort((np.arange(k + 1), dd))[: min(p, k + 1)] + 1
+        assert np.array_equal(NN[k, : len(want)], want) and not NN[k, len(want):].any()
+    revCond = va["U_prep"]["revCond"]
+    assert np.array_equal(revCond[:, -1], np.ones(n, revCond.dtype)) and not (revCond[:, :-1] > 0).any()
+    cp, tau = [1.0, 0.02, 1.5], 0.1
+    plan = G.Plan(lo, revNN, revCond)
+    zord = z[va["ord_z"] - 1]
+    plan.set_data(zord)
+    plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z | G.GPV_WANT_U)
+    s = plan.sums()
+    assert s[6] == 0 and s[7] == n
+    Lent = plan.Lentries()
+    ref = R.U_NZentries(R.max_threads(), n, lo, revNN, np.where(revCond < 0, 0, revCond).astype(np.float64),
+                        np.full(n, tau), np.full(n, tau), "matern", cp)
+    assert ref["n_failed"] == 0
+    res = check_rows(Lent, ref["Lentries"], lo, revNN, revCond, tau, "matern", cp, label="C3 maxmin mode L, all rows")
+    assert res["rows"] == n and res["escaped"] == 0 and res["max_err"] < ROW_TOL, res
+    ll_ref, _ = R.separable_sums_condz_vectorised(revNN, ref["Lentries"], zord, tau)
+    ll = G.loglik_z_from_sums(s, n)
+    assert abs(ll - ll_ref) <= LL_RTOL * abs(ll_ref)
+    assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)

@@ -1,0 +1,117 @@
+"""Reference-RUN parity: outputs of the REAL GPvecchia package on the committed raw inputs
+(tests/golden/make_golden_reference.R -> tests/golden/reference_run/<case>/).
+
+R is not installed in the image this repository is built in, so no such output is committed yet and these tests SKIP
+(the oracle stays "parity unpinned").  The day someone runs the R script on a machine with R and commits
+its outputs, the oracle (CPU) and the HIP path (GPU) are checked against the reference's own numbers with no further edit.
+The inputs the R script reads (tests/golden/raw/) ARE committed and are checked here against the .npz fixtures."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
+NA_INT = -2147483648
+
+
+def _raw(case):
+    d = os.path.join(GOLD, "raw", case)
+    meta = dict(l.strip().split("=", 1) for l in open(os.path.join(d, "meta.txt")))
+    n, dim, m = int(meta["n"]), int(meta["d"]), int(meta["m"])
+    return meta, dict(
+        locs=np.fromfile(os.path.join(d, "locs.f64"), "<f8").reshape((n, dim), order="F"),
+        z=np.fromfile(os.path.join(d, "z.f64"), "<f8"),
+        covparms=np.fromfile(os.path.join(d, "covparms.f64"), "<f8"),
+        nuggets=np.fromfile(os.path.join(d, "nuggets.f64"), "<f8"),
+        ord=np.fromfile(os.path.join(d, "ord.i32"), "<i4"),
+        NNarray=np.fromfile(os.path.join(d, "NNarray.i32"), "<i4").reshape((n, m + 1), order="F"),
+        Cond=np.fromfile(os.path.join(d, "Cond.i32"), "<i4").reshape((n, m + 1), order="F"))
+
+
+def _ref(case):
+    d = os.path.join(GOLD, "reference_run", case)
+    if not os.path.exists(os.path.join(d, "Lentries.f64")):
+        pytest.skip("no reference-run output committed for this case (R is not available in this image; "
+                    "run tests/golden/make_golden_reference.R where it is)")
+    meta, raw = _raw(case)
+    n, p = int(meta["n"]), int(meta["m"]) + 1
+    return meta, raw, dict(Lentries=np.fromfile(os.path.join(d, "Lentries.f64"), "<f8").reshape((n, p), order="F"),
+                           Zentries=np.fromfile(os.path.join(d, "Zentries.f64"), "<f8"),
+                           loglik=float(np.fromfile(os.path.join(d, "loglik.f64"), "<f8")[0]),
+                           U=(np.fromfile(os.path.join(d, "U_i.i32"), "<i4"), np.fromfile(os.path.join(d, "U_j.i32"), "<i4"),
+                              np.fromfile(os.path.join(d, "U_x.f64"), "<f8")))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_raw_inputs_equal_the_npz_fixtures(case):
+    """What the R script would read is exactly what the fixtures hold (regenerate with tests/golden/export_raw_inputs.py)."""
+    g = np.load(os.path.join(GOLD, case + ".npz"), allow_pickle=False)
+    meta, raw = _raw(case)
+    assert np.array_equal(raw["locs"], g["locs"]) and np.array_equal(raw["z"], g["z"])
+    assert np.array_equal(raw["covparms"], g["covparms"]) and np.array_equal(raw["nuggets"], np.atleast_1d(g["nuggets"]))
+    assert np.array_equal(raw["ord"], g["ord"])
+    rev = np.where(raw["NNarray"] == NA_INT, 0, raw["NNarray"])[:, ::-1]
+    assert np.array_equal(rev, g["revNNarray"])
+    assert np.array_equal(np.where(raw["Cond"] == NA_INT, -1, raw["Cond"])[:, ::-1], g["revCond"])
+    assert meta["ordering"] == str(g["ordering"]) and meta["cond.yz"] == str(g["cond"]) and meta["covmodel"] == str(g["covmodel"])
+
+
+def test_r_script_and_bindings_are_present_and_cite_the_reference():
+    root = os.path.dirname(HERE)
+    txt = open(os.path.join(GOLD, "make_golden_reference.R")).read()
+    assert "GPvecchia:::U_NZentries" in txt and "HAS NOT BEEN RUN" in txt
+    for f in ("R/zzz.R", "R/RcppExports_hip.R", "R/plan.R", "src/gpvR_plan.c", "README.md"):
+        assert os.path.exists(os.path.join(root, "bindings", "R", f)), f
+    stubs = open(os.path.join(root, "bindings", "R", "R", "RcppExports_hip.R")).read()
+    for sym in ("gpv_U_NZentries", "gpv_U_NZentries_mat", "gpv_MaternFun", "gpv_EsqeFun"):
+        assert f'"{sym}"' in stubs
+
+
+def test_call_shim_compiles_against_the_public_header():
+    """bindings/R/src/gpvR_plan.c: syntax and prototypes (its calls into include/gpvecchia.h) checked with gcc -fsyntax-only
+    against declaration-only stand-ins of the few R API functions it uses (tests/c_abi/r_api_decls; nothing linked or run)."""
+    import subprocess
+    root = os.path.dirname(HERE)
+    r = subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types",
+                        "-Werror=int-conversion", "-I", os.path.join(root, "include"), "-I", os.path.join(HERE, "c_abi", "r_api_decls"),
+                        os.path.join(root, "bindings", "R", "src", "gpvR_plan.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_run(case):
+    from oracle import r_side as R
+    meta, raw, ref = _ref(case)
+    va = R.vecchia_specify(raw["locs"], int(meta["m"]), ordering=meta["ordering"], cond_yz=meta["cond.yz"])
+    assert np.array_equal(va["ord"], raw["ord"])
+    nug = raw["nuggets"] if raw["nuggets"].size > 1 else float(raw["nuggets"][0])
+    U = R.createU(va, raw["covparms"], nug, meta["covmodel"])
+    L = U["U_entries"]["Lentries"]
+    err = np.abs(L - ref["Lentries"]).max(axis=1) / np.abs(ref["Lentries"]).max(axis=1)
+    assert err.max() < 1e-8, err.max()
+    np.testing.assert_allclose(U["U_entries"]["Zentries"], ref["Zentries"], rtol=1e-15)
+    assert abs(R.vecchia_likelihood_U(raw["z"], U) - ref["loglik"]) <= 1e-8 * abs(ref["loglik"])
+    i, j, x = ref["U"]
+    dense = np.zeros_like(U["U"]); dense[i - 1, j - 1] = x
+    np.testing.assert_allclose(U["U"], dense, rtol=0, atol=1e-8 * np.abs(x).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_hip_path_matches_reference_run(case):
+    import gpvecchia_amd as G
+    if G.device_count() < 1:
+        pytest.fail("gpu-marked test but libgpvecchia_hip sees no HIP device")
+    meta, raw, ref = _ref(case)
+    va = G.vecchia_specify(raw["locs"], int(meta["m"]), ordering=meta["ordering"], cond_yz=meta["cond.yz"])
+    assert np.array_equal(va["ord"], raw["ord"])
+    nug = raw["nuggets"] if raw["nuggets"].size > 1 else float(raw["nuggets"][0])
+    U = G.createU(va, raw["covparms"], nug, meta["covmodel"])
+    err = np.abs(U["Lentries"] - ref["Lentries"]).max(axis=1) / np.abs(ref["Lentries"]).max(axis=1)
+    assert err.max() < 1e-8, err.max()
+    np.testing.assert_allclose(U["Zentries"], ref["Zentries"], rtol=1e-15)
+    ll = G.vecchia_likelihood(raw["z"], va, raw["covparms"], nug, meta["covmodel"])
+    assert abs(ll - ref["loglik"]) <= 1e-8 * abs(ref["loglik"])
