@@ -37,7 +37,7 @@ EXPORTS = [
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
     "gpv_mplan_create_replicas", "gpv_mplan_count", "gpv_mplan_set_data_one", "gpv_mplan_build_posterior",
     "gpv_mplan_eval_each", "gpv_mplan_vl_begin_one", "gpv_mplan_vl_step_each", "gpv_mplan_vl_get_one",
-    "gpv_rccl_version", "gpv_comm_unique_id", "gpv_comm_create", "gpv_comm_destroy", "gpv_plan_set_comm",
+    "gpv_plan_set_observed", "gpv_rccl_version", "gpv_comm_unique_id", "gpv_comm_create", "gpv_comm_destroy", "gpv_plan_set_comm",
 ]
 
 
@@ -111,6 +111,7 @@ def lib():
     L.gpv_mplan_vl_begin_one.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp]
     L.gpv_mplan_vl_step_each.argtypes = [vp, C.c_char_p, dp, C.c_int, ip, dp, ip]
     L.gpv_mplan_vl_get_one.argtypes = [vp, C.c_int, dp, dp, dp]
+    L.gpv_plan_set_observed.argtypes = [vp, ip]
     L.gpv_comm_unique_id.argtypes = [vp]
     L.gpv_comm_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]
     L.gpv_comm_destroy.argtypes = [vp]

@@ -72,6 +72,18 @@ class Plan:
         self.fill_ratio = float(ratio.value)
         return self.fill_ratio
 
+    def set_observed(self, obs_ord):
+        """vecchia.approx$obs in ordered layout (True = the location carries an observation); None = all observed.  With
+        unobserved locations the posterior pass drops 1/tau and z/tau there (U2V + vecchia_mean for plans with prediction
+        locations, R/vecchia_prediction.R:62-126); evaluate with per-location nuggets."""
+        if obs_ord is None:
+            L.check(L.lib().gpv_plan_set_observed(self._h, None), "gpv_plan_set_observed")
+            return
+        o = np.ascontiguousarray(np.asarray(obs_ord, dtype=bool), dtype=np.int32)
+        if o.size != self.Nlocs:
+            raise ValueError("obs must have one entry per ordered location")
+        L.check(L.lib().gpv_plan_set_observed(self._h, L.iptr(o)), "gpv_plan_set_observed")
+
     def posterior_levels(self):
         """Number of levels of the posterior pass's schedule (after build_posterior)."""
         nl = C.c_int()

@@ -337,6 +337,7 @@ struct gpv_plan {
     double *d_avec_base = nullptr;                   // allocation of d_avec: 64 bytes of header, then the n values
     double *d_avec = nullptr, *d_tvec = nullptr, *d_rdiag = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
+    uint8_t *d_obs = nullptr;                        // [Nlocs] ordered layout: 1 = the location carries an observation; nullptr: all do
     std::vector<int32_t> levptr, levptr2;
     std::vector<int> lev_lpc;                        // lanes per column of every level's kernel (16 / 32 / 64), from its row lists
     // the posterior pass as a captured HIP graph (one per {denominator, denominator + mean}): ~140 (280) launches of a few
@@ -434,7 +435,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec_base, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket,
-                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec};
+                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec, pl->d_obs};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -737,6 +738,27 @@ int gpv_plan_set_data(gpv_plan *pl, const double *z_ord)
     return GPV_OK;
 }
 
+int gpv_plan_set_observed(gpv_plan *pl, const int *obs_ord)
+{
+    if (!pl) return GPV_ERR_BAD_ARG;
+    GPV_HIP(hipSetDevice(pl->device));
+    if (pl->last_stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    if (!obs_ord) {                                   // back to "every location is observed"
+        if (pl->d_obs) { GPV_HIP(hipFree(pl->d_obs)); pl->d_obs = nullptr; }
+        return GPV_OK;
+    }
+    std::vector<uint8_t> h((size_t)pl->Nlocs);
+    bool all = true;
+    for (int64_t i = 0; i < pl->Nlocs; ++i) { h[(size_t)i] = obs_ord[i] != 0 ? 1 : 0; all = all && h[(size_t)i]; }
+    if (all) {
+        if (pl->d_obs) { GPV_HIP(hipFree(pl->d_obs)); pl->d_obs = nullptr; }
+        return GPV_OK;
+    }
+    if (!pl->d_obs) GPV_HIP(hipMalloc((void **)&pl->d_obs, (size_t)pl->Nlocs));
+    GPV_HIP(hipMemcpy(pl->d_obs, h.data(), (size_t)pl->Nlocs, hipMemcpyHostToDevice));
+    return GPV_OK;
+}
+
 static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nuggets, int64_t n_nuggets, int flags,
                           void *stream_v, double *d_sums_out)
 {
@@ -772,9 +794,15 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             GPV_HIP(hipMemcpyAsync(pl->d_nug_user, nuggets, sizeof(double) * (size_t)pl->Nlocs,
                                    hipMemcpyHostToDevice, st));
             GPV_HIP(launch_scatter(pl->d_nug_user, pl->d_newpos, pl->Nlocs, pl->d_nuggets, 1, 0, st));
+            // locations without an observation (prediction locations): the set kernel keeps the caller's value (0 in the
+            // reference's nuggets.all.ord, R/createU.R:75-77; such a location is only ever conditioned on as latent, where the
+            // nugget drops out), the posterior pass reads +Inf there: no 1/tau on the diagonal of W = U_y U_y^T, no z/tau in z2
+            if (pl->d_obs) GPV_HIP(launch_mask_unobserved(pl->d_nug_user, pl->d_obs, pl->Nlocs, st));
         } else {
             return GPV_ERR_BAD_ARG;
         }
+        // with unobserved locations the posterior pass needs the per-location form (a constant cannot say "none here")
+        if (pl->d_obs && (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) && pl->nug_is_scalar) return GPV_ERR_BAD_ARG;
     }
     SetArgs a;
     a.rec = pl->d_locs;

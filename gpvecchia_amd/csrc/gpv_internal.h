@@ -81,6 +81,8 @@ hipError_t launch_matern_tab(double nu, int e_lo, int nseg, double scale, double
 hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);
 // dst[pos[i] * stride + offset] = src[i]
 hipError_t launch_scatter(const double *src, const int32_t *pos, int64_t n, double *dst, int stride, int offset, hipStream_t s);
+// x[i] = +Inf where keep[i] == 0 (per-location nuggets as the posterior pass reads them: no observation at a prediction location)
+hipError_t launch_mask_unobserved(double *x, const uint8_t *keep, int64_t n, hipStream_t s);
 hipError_t launch_zentries(const double *nuggets_obsord, int64_t n, double *Z, hipStream_t s);
 hipError_t launch_rows_to_colmajor(const double *src, int ld, int64_t rows, int cols, double *dst, hipStream_t s);
 hipError_t launch_covfun(const double *dist, int64_t n, int cov, double sig0, double sA, double cA, double sB,

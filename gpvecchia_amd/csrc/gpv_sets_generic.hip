@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(kGenericThreads) gpv_sets_generic_kernel(const
         for (int t = 0; t < kNSums; ++t) s_red[t] = acc[t];
     __syncthreads();
     const double mine = tid < kNSums ? s_red[tid] : 0.0;
-    reduce_tail<kGenericThreads>(A, mine, s_red, &s_fail);
+    reduce_tail<kGenericThreads>(&A, mine, s_red, &s_fail);
 }
 
 int generic_max_P() { return kGenericMaxP; }

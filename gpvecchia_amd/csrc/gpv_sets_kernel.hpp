@@ -85,6 +85,12 @@
 #ifndef GPV_OPT_XYSOA
 #define GPV_OPT_XYSOA 1       // three dimensions: staged coordinates coordinate-major (conflict-free partner reads)
 #endif
+#ifndef GPV_OPT_GENA
+#define GPV_OPT_GENA 1        // general nu: tasks whose pairs all have s < 4 and no padding run branch-free table-only rounds; pairs
+#endif                        // outside the LDS window (or coincident points) are flagged bit by bit and redone after the rounds
+#ifndef GPV_OPT_KARGS
+#define GPV_OPT_KARGS 1       // arguments used only in a task's epilogue / after the task loop are read from the kernarg segment THERE
+#endif                        // (scalar loads) instead of living in SGPRs through the loop: the compiler spilled them to VGPR lanes
 #ifndef GPV_OPT_RCP3
 #define GPV_OPT_RCP3 1        // pivot reciprocal: one third-order step on the v_rcp_f64 seed (3 FMAs) instead of two Newton steps (4)
 #endif
@@ -211,6 +217,20 @@ __device__ __forceinline__ void pivot_lane_fix(double &nw, double &pr, double ri
                  : [sv] "=&s"(sv), [nw] "+v"(nw), [pr] "+v"(pr)
                  : [m] "n"(M), [ri] "v"(rinv)
                  : "scc");
+}
+
+// The launch's arguments as they lie in the kernarg segment, through a pointer the compiler cannot see through: a field read
+// through it is a scalar load AT THE POINT OF USE.  Read as the by-value parameter, every field is fetched at kernel entry and
+// stays live to its last use: the ~20 SGPRs of the pointers that only the epilogue of a task and the final reduction need sat
+// in registers through the covariance rounds and the sweep, on top of their own constants and lane masks, and hipcc spilled
+// and reloaded SGPRs through v_writelane / v_readlane — VALU issue slots — around every phase of every task (closed forms:
+// ~100 static in the task loop; general nu: ~350 executed per task, a tenth of its instructions).
+typedef const __attribute__((address_space(4))) SetArgs KSetArgs;
+__device__ __forceinline__ KSetArgs *kargs_now()
+{
+    KSetArgs *k = (KSetArgs *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
 }
 
 template <int P, int D, int COV>
@@ -595,6 +615,34 @@ static __device__ __attribute__((noinline)) void matern_gen_fixup(unsigned long 
     }
 }
 
+// General nu, branch-free rounds (GPV_OPT_GENA): the pairs a lane flagged (bit H_ - s of `flag`: round s) because their segment
+// lies outside the LDS window of the table -- or because the two points coincide, which puts s below every segment -- again:
+// sigma^2 for coincident points (src/Matern.cpp:76), else the table row from global memory, else (outside the table) the
+// quadrature.  One out-of-line copy, rare (about 2 % of the rounds have such a lane at all).
+static __device__ __attribute__((noinline)) void matern_gen_redo(unsigned flag, int rq, int P_, int H_, int dim, unsigned xy0, int xs_row,
+                                                                 int xs_dim, unsigned tr0, double x0, double x1, double x2, double r2init,
+                                                                 double cmul, double sig0, double normcon, double nu, const double *mt,
+                                                                 int mt_base, int mt_nseg)
+{
+    for (int s = 1; s <= H_; ++s) {
+        if (!((flag >> (H_ - s)) & 1u)) continue;
+        const int j = (rq + s < P_) ? rq + s : rq + s - P_;
+        const lds_cdouble *xj = lds_ptr(xy0 + (unsigned)(j * xs_row) * 8u);
+        double df = x0 - xj[0];
+        double r2 = __builtin_fma(df, df, r2init);
+        if (dim > 1) { df = x1 - xj[xs_dim]; r2 = __builtin_fma(df, df, r2); }
+        if (dim > 2) { df = x2 - xj[2 * xs_dim]; r2 = __builtin_fma(df, df, r2); }
+        double v = sig0;
+        if (r2 != r2init) {                                           // (r2init = the smallest normal number: coincident points)
+            const double sd = sqrt_pos(r2);
+            const double sarg = __builtin_fmin(sd * cmul, 1.0e4);
+            v = matern_general_seg(mt, mt_base, mt_nseg, sarg, normcon, nu);
+        }
+        const int hi = rq > j ? rq : j, lo = rq > j ? j : rq;
+        *lds_wptr(tr0 + (unsigned)((hi * (hi + 1)) / 2 + lo) * 8u) = v;
+    }
+}
+
 // covariance from the squared distance; dist == 0 -> sigma^2 exactly
 // (src/Matern.cpp:35,48,63; src/Esqe.cpp:30-31)
 template <int COV>
@@ -735,13 +783,23 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     auto load_ic = [&](const int64_t t) __attribute__((always_inline)) {
         const int64_t kk = t * SPW + sub;
         const bool on = lane_on && t < task_hi && kk < A.rows;
+#if GPV_OPT_KARGS
+        KSetArgs *const Kg = kargs_now();
+        typedef __attribute__((address_space(1))) const int32_t gl_ci32;
+        typedef __attribute__((address_space(1))) const uint8_t gl_cu8;
+        gl_ci32 *const nnp = (gl_ci32 *)Kg->nn;
+        gl_cu8 *const cdp = (gl_cu8 *)Kg->cond;
+#else
+        const int32_t *const nnp = A.nn;
+        const uint8_t *const cdp = A.cond;
+#endif
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {                      // no branches: an idle slot reads entry 0 and is masked
             const int r = i_const + q * LPS;
             const bool ld = on && r < P;
             const int64_t at = ld ? kk * P + r : 0;
-            const int vi = A.nn[at];
-            const int vc = A.cond[at];
+            const int vi = nnp[at];
+            const int vc = cdp[at];
             pidx[q] = ld ? vi : -1;
             pcnd[q] = ld ? vc : 1;                         // (raw byte: flag in bit 0, block position above it)
         }
@@ -757,13 +815,26 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     double2 pr0[RPL], pr1[RPL];
     double pnug[RPL];
     auto load_rec = [&]() __attribute__((always_inline)) {
+#if GPV_OPT_KARGS
+        KSetArgs *const Kg = kargs_now();
+        typedef double v2d_in __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) const v2d_in gl_cd2;
+        typedef __attribute__((address_space(1))) const double gl_cd;
+        gl_cd2 *const recp = (gl_cd2 *)Kg->rec;
+        gl_cd *const nugp = (gl_cd *)Kg->nuggets;
+        const double nugs = Kg->nug_scalar;
+#else
+        const double2 *const recp = reinterpret_cast<const double2 *>(A.rec);
+        const double *const nugp = A.nuggets;
+        const double nugs = A.nug_scalar;
+#endif
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {                      // no branches: a missing neighbour reads record 0 and is masked
             const int at = pidx[q] >= 0 ? pidx[q] : 0;
-            const double2 *rp = reinterpret_cast<const double2 *>(A.rec + (int64_t)at * 4);
-            pr0[q] = rp[0];
-            pr1[q] = rp[1];
-            pnug[q] = (A.nuggets != nullptr) ? A.nuggets[at] : A.nug_scalar;
+            const auto ra = recp[(int64_t)at * 2], rb = recp[(int64_t)at * 2 + 1];
+            pr0[q].x = ra.x; pr0[q].y = ra.y;
+            pr1[q].x = rb.x; pr1[q].y = rb.y;
+            pnug[q] = (nugp != nullptr) ? nugp[at] : nugs;
         }
     };
     if constexpr (PFREC) load_rec();
@@ -954,7 +1025,90 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             double xn[RPL][DD];
 #pragma unroll
             for (int q = 0; q < RPL; ++q) fetch(q, 1, xn[q]);
-            if constexpr (COV == COV_MATERN_GEN) {
+            bool gen_done = false;
+            if constexpr (COV == COV_MATERN_GEN && !MASKED && MTW > 0 && PRESCALE && R2MIN && GPV_OPT_GENA != 0) {
+                // Branch-free rounds for the common task: no padding, and every row of every set within 2 (in units of s, the
+                // coordinates carry 1/range) of the set's own point, so that every PAIR has s < 4 and the table rows it meets
+                // carry exp(-s) (gpv_bessel.hpp).  The rounds then are one basic block: per pair a clamped LDS row, the
+                // polynomial, the store; a lane whose segment lies outside the window records the round in a bit word (coincident
+                // points land there by themselves: their s lies below every segment) and one out-of-line pass redoes those
+                // pairs.  No range test, no exec-masked global fetch, no call, no select on dist == 0 in the rounds: 42 VALU
+                // instructions per pair instead of 48 and none of the lane masks that cost this instantiation its SGPRs.
+                bool near = true;
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    double r2s = 2.2250738585072014e-308;
+#pragma unroll
+                    for (int t = 0; t < D; ++t) {
+                        const double df = xq[q][t] - L.xyat(sub, P - 1, t);
+                        r2s = __builtin_fma(df, df, r2s);
+                    }
+                    near = near && (r2s < 4.0);
+                }
+                if (__builtin_amdgcn_ballot_w64(!near) == 0 && A.mt_nseg > 0) {
+                    gen_done = true;
+                    const int segbase = A.mt_base + A.mt_win;
+                    const unsigned mtl = lds_addr(mt_lds);
+                    unsigned flg[RPL];
+                    double sgn[RPL], rn[RPL][MaternTab::ROW];
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) flg[q] = 0u;
+                    auto stage_a = [&](int s) {
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q) {
+                            double r2 = 2.2250738585072014e-308;
+#pragma unroll
+                            for (int t = 0; t < D; ++t) {
+                                const double df = xq[q][t] - xn[q][t];
+                                r2 = __builtin_fma(df, df, r2);
+                            }
+                            if (s < H) fetch(q, s + 1, xn[q]);
+                            const double sg = __builtin_fmin(sqrt_pos(r2), 1.0e4);
+                            sgn[q] = sg;
+                            const unsigned relu = (unsigned)((__double2hiint(sg) >> (20 - MaternTab::LSPO)) - segbase);
+                            flg[q] = flg[q] + flg[q] + (relu >= (unsigned)MTW ? 1u : 0u);
+                            asm volatile("" : "+v"(flg[q]));          // here, not after the rounds with 2 H segment numbers kept alive
+                            const unsigned relc = relu < (unsigned)MTW ? relu : (unsigned)(MTW - 1);
+                            static_assert(kMtRowLds * 8 == 72, "row stride");
+                            unsigned a64 = mtl + (relc << 6);
+                            asm volatile("" : "+v"(a64));
+                            const lds_cdouble *rowl = lds_ptr(a64 + (relc << 3));
+#pragma unroll
+                            for (int c = 0; c < MaternTab::ROW; ++c) rn[q][c] = rowl[c];
+                        }
+                    };
+                    stage_a(1);
+#pragma unroll
+                    for (int s = 1; s <= H; ++s) {
+                        double sgc[RPL], rc[RPL][MaternTab::ROW];
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q) {
+                            sgc[q] = sgn[q];
+#pragma unroll
+                            for (int c = 0; c < MaternTab::ROW; ++c) rc[q][c] = rn[q][c];
+                        }
+                        if (s < H) stage_a(s + 1);
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q) {
+                            const double v = matern_tab_poly(rc[q], sgc[q]);      // (every s < 4: the row is the covariance itself)
+                            *lds_wptr(((rq[q] < P - s) ? trA[q] : trB[q]) + 8 * s) = v;
+                            trA[q] += rq8[q] + 8 * s;                             // to round s + 1
+                        }
+                    }
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) any = any || (flg[q] != 0u);
+                    if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+                        for (int q = 0; q < RPL; ++q)
+                            matern_gen_redo(flg[q], rq[q], P, H, D, xy0, Lds::XS_ROW, Lds::XS_DIM, tr0, xq[q][0], D > 1 ? xq[q][D > 1 ? 1 : 0] : 0.0,
+                                            D > 2 ? xq[q][D > 2 ? 2 : 0] : 0.0, 2.2250738585072014e-308, 1.0, sig0, sA, sB, A.mt, A.mt_base,
+                                            A.mt_nseg);
+                    }
+                }
+            }
+            if (gen_done) {
+            } else if constexpr (COV == COV_MATERN_GEN) {
                 // General nu, software pipelined by one round: the table rows of round s + 1 (distance -> segment -> LDS reads)
                 // are requested BEFORE the polynomials of round s run, so that the LDS latency of a row sits behind a round of
                 // arithmetic instead of in front of its own Horner chain (VALU busy 64 % against the closed forms' 85 % with the
@@ -1046,7 +1200,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     trA[q] += rq8[q] + 8 * s;                        // to round s + 1
                 }
             }
-            if constexpr (COV == COV_MATERN_GEN) {
+            if (COV == COV_MATERN_GEN && !gen_done) {
                 // the flagged pairs again, exactly (matern_gen_fixup: a real function call, so that the quadrature, its loop and
                 // its library functions exist once per code object and not inside this loop); the lane overwrites what it staged
                 bool any = false;
@@ -1266,14 +1420,26 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         }
 
         // ---- outputs -------------------------------------------------------------------
+#if GPV_OPT_KARGS
+        KSetArgs *const K = kargs_now();                   // output addresses: scalar loads here, not SGPRs held through the task
+        typedef __attribute__((address_space(1))) double gl_double;
+        typedef __attribute__((address_space(1))) const int32_t gl_cint32;
+        gl_double *const outL = (gl_double *)K->Lentries;
+        gl_cint32 *const rowid = (gl_cint32 *)K->rowid;
+        gl_double *const aout = (gl_double *)K->aout;
+#else
+        double *const outL = A.Lentries;
+        const int32_t *const rowid = A.rowid;
+        double *const aout = A.aout;
+#endif
         if (A.flags & 1) {
             const int n0 = P - nmiss;
-            const int64_t kout = set_on ? (int64_t)A.rowid[k] : 0;     // row of Lentries this stored set belongs to
+            const int64_t kout = set_on ? (int64_t)rowid[k] : 0;       // row of Lentries this stored set belongs to
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 if (set_on && row[q] < P) {
                     const int pos = valid[q] ? (row[q] - nmiss) : (n0 + row[q]);   // left-aligned, zero padded (:33,63)
-                    A.Lentries[kout * P + pos] = x[q];
+                    outL[kout * P + pos] = x[q];
                 }
             }
         }
@@ -1287,11 +1453,12 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             // gets a_k below), 16 bytes each; the two addresses come from the header in front of aout
             // (addresses read from memory carry no address space: say "global", or the accesses are FLAT instructions, whose
             // completion the compiler can only wait for with vmcnt(0) & lgkmcnt(0))
-            const unsigned long long *hdr = reinterpret_cast<const unsigned long long *>(A.aout) - 4;
+            typedef __attribute__((address_space(1))) const unsigned long long gl_cu64;
+            gl_cu64 *hdr = (gl_cu64 *)aout - 4;
             Cout = reinterpret_cast<gl_v2d *>(hdr[0]);
             typedef __attribute__((address_space(1))) const int32_t gl_cint;
             const gl_cint *cboff = reinterpret_cast<const gl_cint *>(hdr[1]);
-            cb = set_on ? (int64_t)cboff[A.rowid[k]] : 0;
+            cb = set_on ? (int64_t)cboff[rowid[k]] : 0;
             const bool both = (A.flags & kFlagBoth) != 0;
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
@@ -1318,7 +1485,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const bool good = set_on && !fail;
                 const double tau = nugraw[QO];
                 const double zk = zi[QO];
-                if (A.aout != nullptr && set_on && i == IO) A.aout[A.rowid[k]] = fail ? 0.0 : negmu * rs;
+                if (aout != nullptr && set_on && i == IO) aout[rowid[k]] = fail ? 0.0 : negmu * rs;
                 if (fused && set_on && i == IO) Cout[cb] = v2d_out{fail ? 0.0 : negmu * rs, 0.0};
                 if (A.flags & 2) {
                     const double tv = tau + vlast;
@@ -1363,7 +1530,11 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     static_assert(sizeof(Lds) * W >= sizeof(double) * (W * 64 + 1), "LDS scratch of the final reduction");
     double *scratch = reinterpret_cast<double *>(&lds_all[0]);
     __syncthreads();
-    reduce_tail<W * 64>(A, s, scratch, reinterpret_cast<int *>(scratch + W * 64));
+#if GPV_OPT_KARGS
+    reduce_tail<W * 64>(kargs_now(), s, scratch, reinterpret_cast<int *>(scratch + W * 64));
+#else
+    reduce_tail<W * 64>(&A, s, scratch, reinterpret_cast<int *>(scratch + W * 64));
+#endif
 }
 
 template <int P, int D, int COV>

@@ -101,6 +101,30 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         obs = np.delete(np.asarray(va["obs"], dtype=bool), np.arange(n, 2 * n))
         mu_obs, mu_pred = A.split_mean(mu_ord, dict(ord=va["ord"], obs=obs))
         return dict(mu_obs=mu_obs, mu_pred=mu_pred, var_obs=None, var_pred=None)
+    nrows = va["locsord"].shape[0]
+    if (n < nrows and va["cond_yz"] in ("SGV", "SGVT", "y") and isinstance(covmodel, str) and not np.any(nug == 0)
+            and not va.get("ic0", False) and va["U_prep"]["revNNarray"].shape[1] <= 64 and nug.size in (1, n)):
+        # prediction locations with latent conditioning (the reference's default in one dimension, R/vecchia_specify.R:92-96):
+        # both branches of U2V that factorise (:72-107) are ONE factorisation W = R R^T with no 1/tau at the unobserved
+        # locations (gpv_plan_set_observed): with ordering.pred = 'obspred' R = B on the prediction columns, which is the
+        # reference's shortcut (:84-107) and has no fill under SGV.  Otherwise the structure is built on the FILLED pattern
+        # (symbolic factorisation on the host, once per plan): exact whatever the ordering; beyond the fill bound the host
+        # route below, like the reference's CHOLMOD
+        plan = A._plan_for(va, device)
+        if not plan.has_posterior:
+            if va["cond_yz"] in ("SGV", "SGVT") and va["ord_pred"] == "obspred":
+                plan.build_posterior()       # no fill: R = B on the prediction columns, the observed block is plain SGV
+            else:
+                plan.build_posterior_fill()
+        if plan.has_posterior:
+            plan.set_observed(va["obs"])
+            zpad = np.zeros(nrows)
+            zpad[np.asarray(va["obs"], dtype=bool)] = z[va["ord_z"] - 1]    # ordered layout, 0 where nothing was observed
+            plan.set_data(zpad)
+            nug_all_ord, _, _ = A._ordered_nuggets(va, nug, n)             # 0 at the unobserved locations (R/createU.R:75-77)
+            plan.eval(covmodel, covparms, nug_all_ord, GPV_WANT_MEAN)
+            mu_obs, mu_pred = A.split_mean(plan.posterior_mean(), dict(ord=va["ord"], obs=va["obs"]))
+            return dict(mu_obs=mu_obs, mu_pred=mu_pred, var_obs=None, var_pred=None, route="device")
     U_obj = A.createU(va, covparms, nug, covmodel, device=device)
     mu_ord = A.vecchia_mean_host(z, U_obj)
     if U_obj["zero_nugg"]:

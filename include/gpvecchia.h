@@ -193,6 +193,15 @@ int gpv_plan_build_posterior(gpv_plan *plan, const int *revNNarray, const int *r
  * entries of the latent block (when refused: over the columns processed up to the refusal, a lower bound). */
 int gpv_plan_build_posterior_fill(gpv_plan *plan, const int *revNNarray, const int *revCondOnLatent, double max_fill,
                                   double *fill_ratio);
+/* Plans whose locsord holds locations WITHOUT an observation (prediction locations, R/vecchia_specify.R:119-149), cond.yz in
+ * {SGV, SGVT, y}: obs_ord[k] != 0 iff ordered location k is observed (vecchia.approx$obs); NULL = all observed (the default).
+ * The posterior pass then leaves 1/tau_k out of W_kk and z_k/tau_k out of z2 at unobserved k, which is U2V + vecchia_mean of
+ * R/vecchia_prediction.R:62-126 for BOTH orderings of prediction plans: with ordering.pred = 'obspred' the reference's third
+ * branch (:84-107, prediction columns of U_y unchanged, Cholesky of the observed block only) is what the one factorisation
+ * W = R R^T yields by itself (R = B on the prediction columns).  Evaluate with per-location nuggets (n_nuggets == Nlocs, any value
+ * at the unobserved locations: 0 in the reference, R/createU.R:75-77) and data 0 there; gpv_plan_get_posterior_mean returns
+ * mu.ord over ALL locations (mu.obs and mu.pred after :135-139).  The likelihood sums are not defined for such plans. */
+int gpv_plan_set_observed(gpv_plan *plan, const int *obs_ord);
 int gpv_plan_posterior_levels(gpv_plan *plan, int *n_levels);
 /* blocking: mu.ord (length Nlocs, ordered layout) after an eval with GPV_WANT_MEAN */
 int gpv_plan_get_posterior_mean(gpv_plan *plan, double *mu_ord);

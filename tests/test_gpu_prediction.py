@@ -32,7 +32,7 @@ def _same_specification(va, vb):
 
 @pytest.mark.parametrize("cond,ordering_pred,pred_cond", CASES)
 @pytest.mark.parametrize("ordering,d", [("maxmin", 2), ("none", 3)])
-def test_prediction_plans_match_oracle(cond, ordering_pred, pred_cond, ordering, d):
+def test_prediction_plans_match_oracle(cond, ordering_pred, pred_cond, ordering, d, monkeypatch):
     G = _need_gpu()
     from oracle import r_side as R
     rng = np.random.default_rng(len(cond) + 7 * d)
@@ -60,7 +60,19 @@ def test_prediction_plans_match_oracle(cond, ordering_pred, pred_cond, ordering,
         ll = G.vecchia_likelihood(z, va, cp, tau)
     assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
     mo_ref, mp_ref = R.vecchia_prediction_mean(z, vb, cp, tau, both=True)
-    pred = G.vecchia_prediction(z, va, cp, tau)
+    if cond in ("SGV", "SGVT"):
+        # latent conditioning with prediction locations: U2V (third branch, R/vecchia_prediction.R:84-107) and vecchia_mean run
+        # on the DEVICE (gpv_plan_set_observed); no host factorisation may be called
+        import scipy.sparse.linalg as spla
+
+        def _no_host_factorisation(*a, **k):
+            raise AssertionError("host sparse factorisation called on the device route")
+        monkeypatch.setattr(spla, "splu", _no_host_factorisation)
+        pred = G.vecchia_prediction(z, va, cp, tau)
+        monkeypatch.undo()
+        assert pred.get("route") == "device" and va[("_plan", 0)].has_posterior
+    else:
+        pred = G.vecchia_prediction(z, va, cp, tau)
     assert pred["mu_obs"].shape == (n,) and pred["mu_pred"].shape == (n_p,)
     np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
     np.testing.assert_allclose(pred["mu_pred"], mp_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
@@ -68,6 +80,53 @@ def test_prediction_plans_match_oracle(cond, ordering_pred, pred_cond, ordering,
     K = R.MaternFun(R.rdist(np.vstack([locs, lp])), cp)
     exact = K[n:, :n] @ np.linalg.solve(K[:n, :n] + np.diag(tau), z)
     assert np.sqrt(np.mean((pred["mu_pred"] - exact) ** 2)) < 0.2 * np.std(exact) + 0.05
+
+
+@pytest.mark.parametrize("cond,ordering_pred", [(None, None), ("SGV", "general"), ("SGV", "obspred"), ("y", "general"), ("y", "obspred")])
+def test_one_dimensional_prediction_plans_run_on_the_device(cond, ordering_pred, monkeypatch):
+    """One dimension: the reference's defaults with prediction locations are ordering = 'coord', cond.yz = 'SGV',
+    ordering.pred = 'general' (R/vecchia_specify.R:83-96,124-126).  The factor of W is banded there (no or little fill), so
+    every latent-conditioning mode runs U2V + vecchia_mean on the device, for both orderings of the prediction locations."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    import scipy.sparse.linalg as spla
+    rng = np.random.default_rng(31)
+    n, n_p, m = 700, 250, 8
+    locs, lp = rng.random((n, 1)), rng.random((n_p, 1))
+    cp = [1.1, 0.05, 0.5]          # (exponential: a smooth kernel on 700 points of a line gives blocks with cond ~1e9, and the
+    tau = 0.05 + 0.1 * rng.random(n)   #  posterior solve amplifies their 1e-7 differences between two correct factorisations)
+    z = np.linalg.cholesky(R.MaternFun(R.rdist(locs), cp) + np.diag(tau)) @ rng.standard_normal(n)
+    kw = dict(locs_pred=lp)
+    if cond is not None:
+        kw.update(cond_yz=cond, ordering_pred=ordering_pred)
+    vb = R.vecchia_specify(locs, m, **kw)
+    va = G.vecchia_specify(locs, m, **kw)
+    _same_specification(va, vb)
+    if cond is None:
+        assert va["cond_yz"] == "SGV" and va["ord_pred"] == "general"
+    mo_ref, mp_ref = R.vecchia_prediction_mean(z, vb, cp, tau, both=True)
+
+    def _no_host_factorisation(*a, **k):
+        raise AssertionError("host sparse factorisation called on the device route")
+    monkeypatch.setattr(spla, "splu", _no_host_factorisation)
+    pred = G.vecchia_prediction(z, va, cp, tau)
+    monkeypatch.undo()
+    assert pred.get("route") == "device"
+    sc = np.abs(mo_ref).max()
+    np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8 * sc)
+    np.testing.assert_allclose(pred["mu_pred"], mp_ref, rtol=0, atol=1e-8 * sc)
+    # and the host route (createU + SuperLU, what the reference's Matrix calls do) gives the same numbers
+    from gpvecchia_amd import api as A
+    U_obj = A.createU(va, cp, tau)
+    mo_h, mp_h = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)
+    np.testing.assert_allclose(pred["mu_pred"], mp_h, rtol=0, atol=1e-9 * sc)
+    np.testing.assert_allclose(pred["mu_obs"], mo_h, rtol=0, atol=1e-9 * sc)
+    # a second evaluation with other parameters reuses the plan and its structure
+    cp2, tau2 = [0.7, 0.08, 0.5], 0.2
+    pred2 = G.vecchia_prediction(z, va, cp2, tau2)
+    mo2, mp2 = R.vecchia_prediction_mean(z, vb, cp2, tau2, both=True)
+    assert pred2.get("route") == "device"
+    np.testing.assert_allclose(pred2["mu_pred"], mp2, rtol=0, atol=1e-8 * np.abs(mo2).max())
 
 
 class _nullcontext:
