@@ -320,18 +320,40 @@ class ReplicaPlans:
         return np.array([loglik_from_sums(r, self.Nlocs) for r in s])
 
 
-_R_LAYOUT_CACHE = []          # [(revNNarray, revCond, nn_r, cd_r)]: the R-layout copies of the last two index-array pairs
+_R_LAYOUT_CACHE = []          # [(weakref(revNNarray), weakref(revCond), fingerprint, nn_r, cd_r)] of the last two index-array pairs
+
+
+def _fingerprint(a):
+    """Cheap content fingerprint of an index array: shape, dtype and a CRC of a strided sample of at most ~64 K entries plus
+    the first and last rows (an in-place edit of the array between two calls almost surely changes it; the library's own
+    plan cache hashes the full content behind this)."""
+    import zlib
+    a = np.asarray(a)
+    flat = a.reshape(-1)
+    step = max(1, flat.size // 65536)
+    sample = np.ascontiguousarray(flat[::step])
+    crc = zlib.crc32(sample.tobytes())
+    if a.ndim == 2 and a.shape[0] > 0:
+        crc = zlib.crc32(np.ascontiguousarray(a[0]).tobytes(), crc)
+        crc = zlib.crc32(np.ascontiguousarray(a[-1]).tobytes(), crc)
+    return (a.shape, a.dtype.str, crc)
 
 
 def _r_layout_cached(revNNarray, revCond):
     """Column-major int32 copies (R's representation) of the two index arrays, kept for the arrays last seen: createU hands
     the SAME objects to U_NZentries at every optimiser step, and converting 2 x 31e6 entries costs ~60 ms, six times the
-    library call.  Keyed by object identity: arrays are treated as immutable once handed over (the reference's R semantics)."""
-    for a, b, nn_r, cd_r in _R_LAYOUT_CACHE:
-        if a is revNNarray and b is revCond:
+    library call.  A hit needs the same two objects (held by weak reference: the cache keeps no caller array alive) AND an
+    unchanged content fingerprint, so an array edited in place between two calls is converted again."""
+    import weakref
+    fp = (_fingerprint(revNNarray), _fingerprint(revCond))
+    for wa, wb, f, nn_r, cd_r in _R_LAYOUT_CACHE:
+        if wa() is revNNarray and wb() is revCond and f == fp:
             return nn_r, cd_r
     nn_r, cd_r = L.as_r_int_matrix(revNNarray), _cond_to_r(revCond)
-    _R_LAYOUT_CACHE.insert(0, (revNNarray, revCond, nn_r, cd_r))
+    try:
+        _R_LAYOUT_CACHE.insert(0, (weakref.ref(revNNarray), weakref.ref(revCond), fp, nn_r, cd_r))
+    except TypeError:                                                  # not weakly referenceable (a list, ...): do not cache
+        return nn_r, cd_r
     del _R_LAYOUT_CACHE[2:]
     return nn_r, cd_r
 

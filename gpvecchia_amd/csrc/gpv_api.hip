@@ -1801,6 +1801,18 @@ int gpv_plan_get_sums(gpv_plan *pl, double *sums)
     return GPV_OK;
 }
 
+// developer aid (tools/wave_timeline.py, builds with -DGPV_TRACE_TIMES): `count` doubles of the per-workgroup partial-sum buffer
+// from `offset` on; not part of the public header
+extern "C" int gpv_plan_debug_block_sums(gpv_plan *pl, int64_t offset, int64_t count, double *out, int *grid)
+{
+    if (!pl || !out || offset < 0 || count < 0 || offset + count > (int64_t)kMaxGrid * kNSums) return GPV_ERR_BAD_ARG;
+    GPV_HIP(hipSetDevice(pl->device));
+    if (pl->last_stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    GPV_HIP(hipMemcpy(out, pl->d_block + offset, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost));
+    if (grid) *grid = pl->grid;
+    return GPV_OK;
+}
+
 int gpv_plan_get_Lentries(gpv_plan *pl, double *Lentries)
 {
     if (!pl || !Lentries) return GPV_ERR_BAD_ARG;

@@ -59,6 +59,8 @@ struct SetArgs {
     int mt_base, mt_nseg;    //   segment of s = (bits(s) >> 49) - mt_base (gpv_bessel.hpp, matern_tab_segment)
     int mt_full;             //   1: the table covers every pair distance of the plan (no range test per pair needed)
     int mt_win;              //   first table row of the window the workgroups keep in LDS (where the distances concentrate)
+    int share_old, share_young;   // set by the launcher (0, 0 = equal shares): task slots per round of a wavefront of the workgroups
+                                  // dispatched first / second when there is exactly one workgroup per resident slot (gpv_sets_kernel.hpp)
 };
 
 // launch the conditioning-set kernel compiled for row length P (one of gpv_plist.h); the grid is chosen from

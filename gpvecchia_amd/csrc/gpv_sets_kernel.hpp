@@ -35,6 +35,7 @@
 #include "gpv_internal.h"
 #include "gpv_bessel.hpp"
 #include "gpv_reduce_tail.hpp"
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -85,9 +86,15 @@
 #ifndef GPV_OPT_XYSOA
 #define GPV_OPT_XYSOA 1       // three dimensions: staged coordinates coordinate-major (conflict-free partner reads)
 #endif
-#ifndef GPV_OPT_GENA
-#define GPV_OPT_GENA 1        // general nu: tasks whose pairs all have s < 4 and no padding run branch-free table-only rounds; pairs
-#endif                        // outside the LDS window (or coincident points) are flagged bit by bit and redone after the rounds
+#ifndef GPV_OPT_GEN_NOLIVE
+#define GPV_OPT_GEN_NOLIVE 1  // general nu: no select on dist == 0 in the rounds; coincident points have s below every table segment,
+#endif                        // are flagged like any pair outside the table and get sigma^2 from the out-of-line pass
+#ifndef GPV_OPT_PRIO
+#define GPV_OPT_PRIO 0        // a pseudo-random wave priority (s_setprio 0..3) per task: measured, superseded by GPV_OPT_UNEVEN
+#endif
+#ifndef GPV_OPT_UNEVEN
+#define GPV_OPT_UNEVEN 1      // one workgroup per resident slot: the workgroups dispatched first take two tasks for every one of the
+#endif                        // workgroups dispatched second (the older wavefront of a SIMD is issued first: see the task loop)
 #ifndef GPV_OPT_KARGS
 #define GPV_OPT_KARGS 1       // arguments used only in a task's epilogue / after the task loop are read from the kernarg segment THERE
 #endif                        // (scalar loads) instead of living in SGPRs through the loop: the compiler spilled them to VGPR lanes
@@ -598,7 +605,7 @@ __device__ __forceinline__ double matern_table_value(const double (&r)[MaternTab
 // xy0 / tr0: LDS byte addresses of the set's staged coordinates and triangle; xs_row / xs_dim: the coordinates' strides.
 static __device__ __attribute__((noinline)) void matern_gen_fixup(unsigned long long need, int rq, int P_, int H_, int dim, unsigned xy0,
                                                                   int xs_row, int xs_dim, unsigned tr0, double x0, double x1, double x2,
-                                                                  double r2init, double cmul, double normcon, double nu)
+                                                                  double r2init, double cmul, double normcon, double nu, double sig0)
 {
     for (int s = 1; s <= H_; ++s) {
         if (!((need >> (s - 1)) & 1ull)) continue;
@@ -611,35 +618,9 @@ static __device__ __attribute__((noinline)) void matern_gen_fixup(unsigned long 
         const double sd = sqrt(__builtin_fmax(r2, 2.2250738585072014e-308));
         const double sarg = __builtin_fmin(sd * cmul, 1.0e4);
         const int hi = rq > j ? rq : j, lo = rq > j ? j : rq;
-        *lds_wptr(tr0 + (unsigned)((hi * (hi + 1)) / 2 + lo) * 8u) = matern_general(sarg, normcon, nu);
-    }
-}
-
-// General nu, branch-free rounds (GPV_OPT_GENA): the pairs a lane flagged (bit H_ - s of `flag`: round s) because their segment
-// lies outside the LDS window of the table -- or because the two points coincide, which puts s below every segment -- again:
-// sigma^2 for coincident points (src/Matern.cpp:76), else the table row from global memory, else (outside the table) the
-// quadrature.  One out-of-line copy, rare (about 2 % of the rounds have such a lane at all).
-static __device__ __attribute__((noinline)) void matern_gen_redo(unsigned flag, int rq, int P_, int H_, int dim, unsigned xy0, int xs_row,
-                                                                 int xs_dim, unsigned tr0, double x0, double x1, double x2, double r2init,
-                                                                 double cmul, double sig0, double normcon, double nu, const double *mt,
-                                                                 int mt_base, int mt_nseg)
-{
-    for (int s = 1; s <= H_; ++s) {
-        if (!((flag >> (H_ - s)) & 1u)) continue;
-        const int j = (rq + s < P_) ? rq + s : rq + s - P_;
-        const lds_cdouble *xj = lds_ptr(xy0 + (unsigned)(j * xs_row) * 8u);
-        double df = x0 - xj[0];
-        double r2 = __builtin_fma(df, df, r2init);
-        if (dim > 1) { df = x1 - xj[xs_dim]; r2 = __builtin_fma(df, df, r2); }
-        if (dim > 2) { df = x2 - xj[2 * xs_dim]; r2 = __builtin_fma(df, df, r2); }
-        double v = sig0;
-        if (r2 != r2init) {                                           // (r2init = the smallest normal number: coincident points)
-            const double sd = sqrt_pos(r2);
-            const double sarg = __builtin_fmin(sd * cmul, 1.0e4);
-            v = matern_general_seg(mt, mt_base, mt_nseg, sarg, normcon, nu);
-        }
-        const int hi = rq > j ? rq : j, lo = rq > j ? j : rq;
-        *lds_wptr(tr0 + (unsigned)((hi * (hi + 1)) / 2 + lo) * 8u) = v;
+        // two points at one location: sigma^2 exactly (src/Matern.cpp:76); r2 is then still the value the sum started from
+        const bool same = (r2 == r2init) || (r2 == 0.0);
+        *lds_wptr(tr0 + (unsigned)((hi * (hi + 1)) / 2 + lo) * 8u) = same ? sig0 : matern_general(sarg, normcon, nu);
     }
 }
 
@@ -676,9 +657,16 @@ __device__ __forceinline__ bool gen_fetch(double r2, double cA, const SetArgs &A
 {
     constexpr double kTiny = 2.2250738585072014e-308;
     const double sd = sqrt_pos(R2MIN ? r2 : __builtin_fmax(r2, kTiny));
-    const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
     // (s clamped like t of the closed forms; s^nu K_nu(s) is 0 in FP64 from s ~ 800 for every nu <= 60)
     sg = __builtin_fmin(SCALED ? sd : sd * cA, 1.0e4);
+    if constexpr (R2MIN && GPV_OPT_GEN_NOLIVE != 0) {
+        // coincident points: r2 is the smallest normal number, s ~ 1e-154 / range lies below every segment a table can have, so
+        // the pair is flagged like any other outside the table and matern_gen_fixup writes sigma^2: no compare and no
+        // select per pair for a case that needs two observations at one location
+        matern_table_fetch<MTW>(A, mt_lds, sg, pair_used, r, need, bit);
+        return true;
+    }
+    const bool live = R2MIN ? (r2 != kTiny) : (r2 != 0.0);
     matern_table_fetch<MTW>(A, mt_lds, sg, live && pair_used, r, need, bit);
     return live;
 }
@@ -743,6 +731,11 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
+#ifdef GPV_TRACE_TIMES
+    // developer build (tools/wave_timeline.py): wall-clock stamps of every wavefront in the unused tail of block_sums
+    unsigned long long tr_t[4] = {(unsigned long long)wall_clock64(), 0ull, 0ull, 0ull};
+    int tr_tasks = 0;
+#endif
     const int sub_raw = lane / LPS;
     const bool lane_on = sub_raw < SPW;
     const int sub = lane_on ? sub_raw : SPW - 1;
@@ -804,7 +797,37 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             pcnd[q] = ld ? vc : 1;                         // (raw byte: flag in bit 0, block position above it)
         }
     };
-    load_ic(task_lo + (int64_t)jb * W + wv);
+    // Which tasks a wavefront takes.  Normally task_lo + (jb W + wv) + k nbx W.  With one workgroup per resident slot (two
+    // workgroups of four wavefronts per CU; short launches: one rank's shard of an 8-GPU job, BASELINE config C2) the two
+    // wavefronts of a SIMD are one from the workgroup dispatched first (blockIdx < gridDim / 2: workgroups b and
+    // b + gridDim / 2 land on the same CU, tools/ubench/placement.hip) and one from the workgroup dispatched second, and the
+    // issue arbiter serves the OLDER wavefront first: in this VALU-issue-bound kernel it runs 6.9 us per task and its
+    // partner 13.4 (tools/wave_timeline.py, 125 000 rows, m = 30).  With equal shares the older one was done after 113 of
+    // 162 us and the younger finished ALONE, at 6.8 us per task where the pair together retires one every 4.7: a third of
+    // the launch at 3/4 of the SIMD's throughput.  So the shares follow the rates: an older wavefront owns TWO of the
+    // interleaved task slots, a younger one ONE, and the pair leaves together.  Static, hence bit-for-bit reproducible; if
+    // the placement were ever different only the balance would suffer, not the result.
+    // Shares (so, sy) = A.share_old, A.share_young task slots per round for an older / a younger wavefront (2, 1 for the
+    // closed forms).  The slots are laid out in LAYERS — layer l holds one slot of every older wavefront and, for l < sy, one
+    // of every younger one — so that the tasks left over after the last full round go one each to as many wavefronts as
+    // possible instead of two to a few.
+    const bool uneven = GPV_OPT_UNEVEN != 0 && A.share_old > A.share_young && A.share_young > 0 && nx == 8 && (nbx & 1) == 0;
+    const int nold = nbx >> 1;
+    const bool elder = jb < nold;
+    const int so = uneven ? A.share_old : 1, sy = uneven ? A.share_young : 1;
+    const int64_t lay_full = (int64_t)nbx * W, lay_old = (int64_t)nold * W;          // slots of a layer with / without the younger waves
+    const int64_t vslots = uneven ? lay_full * sy + lay_old * (so - sy) : lay_full;
+    const int64_t vfirst = !uneven ? (int64_t)jb * W + wv : (elder ? (int64_t)jb * W + wv : lay_old + (int64_t)(jb - nold) * W + wv);
+    const int my_layers = (uneven && elder) ? so : sy;
+    // step from the wavefront's slot in layer l to its next one: into layer l + 1, or from its last layer into layer 0 of the next round
+    auto step_from = [&](int l) -> int64_t {
+        if (!uneven) return lay_full;
+        if (l + 1 < my_layers) return (l < sy) ? lay_full : lay_old;
+        int64_t off = 0;                                              // offset of layer l within a round
+        for (int t = 0; t < l; ++t) off += (t < sy) ? lay_full : lay_old;
+        return vslots - off;
+    };
+    load_ic(task_lo + vfirst);
     // DPP geometries, location records: the records of the next task are requested from the middle of the sweep, when half
     // of the block's registers are free again and nothing else is in flight
     constexpr bool PFREC = G::DPP && D != 0 && COV != COV_DENSE;
@@ -838,13 +861,31 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         }
     };
     if constexpr (PFREC) load_rec();
-    for (int64_t task = task_lo + (int64_t)jb * W + wv; task < task_hi; task += (int64_t)nbx * W) {
+    int task_layer = 0;
+    for (int64_t task = task_lo + vfirst, task_next; task < task_hi; task = task_next) {
+        task_next = task + step_from(task_layer);
+        task_layer = (task_layer + 1 < my_layers) ? task_layer + 1 : 0;
         const int64_t k = task * SPW + sub;
         const bool set_on = lane_on && (k < A.rows);
         // re-materialise the lane's row index per task: otherwise hipcc hoists all P (row == j) lane masks
         // out of the task loop (2P SGPRs -> SGPR spills through v_writelane/v_readlane inside the sweep)
         int i = i_const;
         asm volatile("" : "+v"(i));
+#if GPV_OPT_PRIO
+        // The two wavefronts that share a SIMD come from two workgroups; the issue arbiter prefers the OLDER wave on equal
+        // priority, and this kernel is bound by VALU issue: measured (tools/wave_timeline.py, 125 000 rows, one workgroup per
+        // slot) the older wave runs 7.1 us per task, the younger 13.8, the older one is done after 113 of 170 us and the
+        // younger finishes ALONE at 6.8 us per task where the pair managed 4.7: a third of the kernel at 3/4 of the SIMD's
+        // throughput.  A pseudo-random priority per task (a hash of the task number: no two partners follow the same sequence)
+        // makes either wave the preferred one about as often, both progress at about the same rate and leave together.
+        // Which task a wave runs, and in which order its sums accumulate, does not change: results are bit for bit the same.
+        switch (((unsigned)task * 2654435761u) >> 30) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+        }
+#endif
 
         // ---- gather: indices, cond flags, coordinates, nugget, data -------------------
         int row[RPL], idx[RPL], cndraw[RPL], wslot[RPL];     // cndraw: the cond byte as stored (flag in bit 0, block position above it)
@@ -926,7 +967,11 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         }
         const int nmiss = P - nvalid;
         wave_sync();
-        load_ic(task + (int64_t)nbx * W);                     // the next task's indices travel during this task
+#ifdef GPV_TRACE_TIMES
+        if (tr_t[1] == 0ull) tr_t[1] = wall_clock64();        // first task gathered (prologue + two trips to memory behind us)
+        ++tr_tasks;
+#endif
+        load_ic(task_next);                                   // the next task's indices travel during this task
 
         // ---- covariance: every unordered pair once, circulant pairing ------------------
         constexpr int H = P / 2;
@@ -1025,90 +1070,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             double xn[RPL][DD];
 #pragma unroll
             for (int q = 0; q < RPL; ++q) fetch(q, 1, xn[q]);
-            bool gen_done = false;
-            if constexpr (COV == COV_MATERN_GEN && !MASKED && MTW > 0 && PRESCALE && R2MIN && GPV_OPT_GENA != 0) {
-                // Branch-free rounds for the common task: no padding, and every row of every set within 2 (in units of s, the
-                // coordinates carry 1/range) of the set's own point, so that every PAIR has s < 4 and the table rows it meets
-                // carry exp(-s) (gpv_bessel.hpp).  The rounds then are one basic block: per pair a clamped LDS row, the
-                // polynomial, the store; a lane whose segment lies outside the window records the round in a bit word (coincident
-                // points land there by themselves: their s lies below every segment) and one out-of-line pass redoes those
-                // pairs.  No range test, no exec-masked global fetch, no call, no select on dist == 0 in the rounds: 42 VALU
-                // instructions per pair instead of 48 and none of the lane masks that cost this instantiation its SGPRs.
-                bool near = true;
-#pragma unroll
-                for (int q = 0; q < RPL; ++q) {
-                    double r2s = 2.2250738585072014e-308;
-#pragma unroll
-                    for (int t = 0; t < D; ++t) {
-                        const double df = xq[q][t] - L.xyat(sub, P - 1, t);
-                        r2s = __builtin_fma(df, df, r2s);
-                    }
-                    near = near && (r2s < 4.0);
-                }
-                if (__builtin_amdgcn_ballot_w64(!near) == 0 && A.mt_nseg > 0) {
-                    gen_done = true;
-                    const int segbase = A.mt_base + A.mt_win;
-                    const unsigned mtl = lds_addr(mt_lds);
-                    unsigned flg[RPL];
-                    double sgn[RPL], rn[RPL][MaternTab::ROW];
-#pragma unroll
-                    for (int q = 0; q < RPL; ++q) flg[q] = 0u;
-                    auto stage_a = [&](int s) {
-#pragma unroll
-                        for (int q = 0; q < RPL; ++q) {
-                            double r2 = 2.2250738585072014e-308;
-#pragma unroll
-                            for (int t = 0; t < D; ++t) {
-                                const double df = xq[q][t] - xn[q][t];
-                                r2 = __builtin_fma(df, df, r2);
-                            }
-                            if (s < H) fetch(q, s + 1, xn[q]);
-                            const double sg = __builtin_fmin(sqrt_pos(r2), 1.0e4);
-                            sgn[q] = sg;
-                            const unsigned relu = (unsigned)((__double2hiint(sg) >> (20 - MaternTab::LSPO)) - segbase);
-                            flg[q] = flg[q] + flg[q] + (relu >= (unsigned)MTW ? 1u : 0u);
-                            asm volatile("" : "+v"(flg[q]));          // here, not after the rounds with 2 H segment numbers kept alive
-                            const unsigned relc = relu < (unsigned)MTW ? relu : (unsigned)(MTW - 1);
-                            static_assert(kMtRowLds * 8 == 72, "row stride");
-                            unsigned a64 = mtl + (relc << 6);
-                            asm volatile("" : "+v"(a64));
-                            const lds_cdouble *rowl = lds_ptr(a64 + (relc << 3));
-#pragma unroll
-                            for (int c = 0; c < MaternTab::ROW; ++c) rn[q][c] = rowl[c];
-                        }
-                    };
-                    stage_a(1);
-#pragma unroll
-                    for (int s = 1; s <= H; ++s) {
-                        double sgc[RPL], rc[RPL][MaternTab::ROW];
-#pragma unroll
-                        for (int q = 0; q < RPL; ++q) {
-                            sgc[q] = sgn[q];
-#pragma unroll
-                            for (int c = 0; c < MaternTab::ROW; ++c) rc[q][c] = rn[q][c];
-                        }
-                        if (s < H) stage_a(s + 1);
-#pragma unroll
-                        for (int q = 0; q < RPL; ++q) {
-                            const double v = matern_tab_poly(rc[q], sgc[q]);      // (every s < 4: the row is the covariance itself)
-                            *lds_wptr(((rq[q] < P - s) ? trA[q] : trB[q]) + 8 * s) = v;
-                            trA[q] += rq8[q] + 8 * s;                             // to round s + 1
-                        }
-                    }
-                    bool any = false;
-#pragma unroll
-                    for (int q = 0; q < RPL; ++q) any = any || (flg[q] != 0u);
-                    if (__builtin_amdgcn_ballot_w64(any) != 0) {
-#pragma unroll
-                        for (int q = 0; q < RPL; ++q)
-                            matern_gen_redo(flg[q], rq[q], P, H, D, xy0, Lds::XS_ROW, Lds::XS_DIM, tr0, xq[q][0], D > 1 ? xq[q][D > 1 ? 1 : 0] : 0.0,
-                                            D > 2 ? xq[q][D > 2 ? 2 : 0] : 0.0, 2.2250738585072014e-308, 1.0, sig0, sA, sB, A.mt, A.mt_base,
-                                            A.mt_nseg);
-                    }
-                }
-            }
-            if (gen_done) {
-            } else if constexpr (COV == COV_MATERN_GEN) {
+            if constexpr (COV == COV_MATERN_GEN) {
                 // General nu, software pipelined by one round: the table rows of round s + 1 (distance -> segment -> LDS reads)
                 // are requested BEFORE the polynomials of round s run, so that the LDS latency of a row sits behind a round of
                 // arithmetic instead of in front of its own Horner chain (VALU busy 64 % against the closed forms' 85 % with the
@@ -1155,7 +1117,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #pragma unroll
                     for (int q = 0; q < RPL; ++q) {
                         double v = matern_table_value(rc[q], sgc[q]);
-                        v = livec[q] ? v : sig0;                     // src/Matern.cpp:76 (a select, not a branch round the polynomial)
+                        if constexpr (!(R2MIN && GPV_OPT_GEN_NOLIVE != 0)) v = livec[q] ? v : sig0;   // src/Matern.cpp:76 (else: matern_gen_fixup)
                         if constexpr (MASKED) v = usedc[q] ? v : 0.0;
                         *lds_wptr(((rq[q] < P - s) ? trA[q] : trB[q]) + 8 * s) = v;
                         trA[q] += rq8[q] + 8 * s;                    // to round s + 1
@@ -1200,7 +1162,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     trA[q] += rq8[q] + 8 * s;                        // to round s + 1
                 }
             }
-            if (COV == COV_MATERN_GEN && !gen_done) {
+            if constexpr (COV == COV_MATERN_GEN) {
                 // the flagged pairs again, exactly (matern_gen_fixup: a real function call, so that the quadrature, its loop and
                 // its library functions exist once per code object and not inside this loop); the lane overwrites what it staged
                 bool any = false;
@@ -1211,7 +1173,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     for (int q = 0; q < RPL; ++q)
                         matern_gen_fixup(need[q], rq[q], P, H, D, xy0, Lds::XS_ROW, Lds::XS_DIM, tr0, xq[q][0], D > 1 ? xq[q][D > 1 ? 1 : 0] : 0.0,
                                          D > 2 ? xq[q][D > 2 ? 2 : 0] : 0.0, R2MIN ? 2.2250738585072014e-308 : 0.0, PRESCALE ? 1.0 : cA,
-                                         sA, sB);
+                                         sA, sB, sig0);
                 }
             }
         };
@@ -1507,6 +1469,9 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         acc_fail += (set_on && fail) ? 1 : 0;
         acc_rows += set_on ? 1 : 0;
     }
+#ifdef GPV_TRACE_TIMES
+    tr_t[2] = wall_clock64();
+#endif
     if (lane_on && i_const == IO) {
         double *ac = L.acc[sub];
         ac[0] = (A.flags & 4) ? lg_d.value() : 0.0;
@@ -1535,25 +1500,53 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #else
     reduce_tail<W * 64>(&A, s, scratch, reinterpret_cast<int *>(scratch + W * 64));
 #endif
+#ifdef GPV_TRACE_TIMES
+    if (lane == 0 && (int64_t)blockIdx.x * W + wv < kMaxGrid / 2) {
+        tr_t[3] = wall_clock64();
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(A.block_sums) + ((int64_t)kMaxGrid / 2 + blockIdx.x * W + wv) * kNSums;
+        o[0] = tr_t[0]; o[1] = tr_t[1]; o[2] = tr_t[2]; o[3] = tr_t[3]; o[4] = (unsigned long long)tr_tasks;
+        o[5] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));    // HW_ID
+    }
+#endif
 }
 
 template <int P, int D, int COV>
-hipError_t launch_sets_PDC(const SetArgs &a, int cus, int *grid_out, hipStream_t stream)
+hipError_t launch_sets_PDC(const SetArgs &a_in, int cus, int *grid_out, hipStream_t stream)
 {
     constexpr int W = wpb<P, D, COV>();
-    const int64_t tasks = (a.rows + Geo<P>::SPW - 1) / Geo<P>::SPW;
+    const int64_t tasks = (a_in.rows + Geo<P>::SPW - 1) / Geo<P>::SPW;
     const int64_t need = (tasks + W - 1) / W;
-    // workgroups per resident slot: every wavefront pays a prologue of two dependent trips to memory (indices, then records)
-    // before its first task, so few, long-lived wavefronts win while the tail stays short against the whole launch
-    // (measured: n = 1e5, m = 20: 0.110 ms with one workgroup per slot against 0.116 with four; n = 1e6, m = 30: 1.54 against
-    // 1.48: below ~48 tasks per resident wavefront the prologue outweighs the tail)
+    // Grid.  Every wavefront pays a prologue of two dependent trips to memory (indices, then records) before its first task, so
+    // few, long-lived wavefronts win as long as they finish together.
+    //   * Two four-wave workgroups per CU (every instantiation whose LDS allows it): ONE workgroup per resident slot, and
+    //     the task shares of the two wavefronts of a SIMD follow their issue rates (share_old : share_young, see the task
+    //     loop of the kernel): 2 : 1 for the closed forms, 3 : 2 for general nu (its rounds wait on LDS more and share the
+    //     SIMD more evenly) and for launches of fewer than 6 tasks per slot (the prologue, which both waves sit out side by
+    //     side, weighs more); below 3 tasks per slot equal shares.  Measured (tools/short_launch.py, same library, switches
+    //     GPV_NO_UNEVEN / GPV_SHARES / GPV_GRID_MULT; profiles/r04_shares_*.txt): n = 1e6, m = 30: 1223 us with four workgroups
+    //     per slot and equal shares (the round-3 choice), 1298 with one per slot and equal shares, 1187 with one per slot
+    //     and 2 : 1; 125 000 rows (one rank of eight): 172 -> 159 us; m = 20, n = 1e5: 96.8 -> 92.1; general nu, n = 1e6:
+    //     1721 -> 1666.
+    //   * otherwise (single-wave workgroups, m + 1 > 48): one workgroup per slot below 48 tasks per slot, four above.
     static const int mult_env = getenv("GPV_GRID_MULT") ? atoi(getenv("GPV_GRID_MULT")) : 0;
+    static const bool no_uneven = getenv("GPV_NO_UNEVEN") != nullptr;
+    static const char *shares_env = getenv("GPV_SHARES");            // developer aid: "3,2"
     const int64_t slots = (int64_t)cus * blocks_per_cu<P, D, COV>() * W;
-    const int mult = mult_env > 0 ? mult_env : (tasks < 48 * slots ? 1 : 4);
+    const bool paired = !no_uneven && W == 4 && blocks_per_cu<P, D, COV>() == 2 && (cus % 8) == 0 && tasks >= 3 * slots;
+    const int mult = mult_env > 0 ? mult_env : (paired ? 1 : (tasks < 48 * slots ? 1 : 4));
     int64_t cap = (int64_t)cus * blocks_per_cu<P, D, COV>() * mult;    // grid-stride beyond
     if (cap > kMaxGrid) cap = kMaxGrid;
     const int grid = (int)(need < cap ? (need < 1 ? 1 : need) : cap);
     if (grid_out) *grid_out = grid;
+    SetArgs a = a_in;
+    a.share_old = a.share_young = 0;
+    if (paired && (int64_t)grid == (int64_t)cus * 2) {
+        const bool two_one = COV != COV_MATERN_GEN && tasks >= 6 * slots;
+        a.share_old = two_one ? 2 : 3;
+        a.share_young = two_one ? 1 : 2;
+        if (shares_env) (void)sscanf(shares_env, "%d,%d", &a.share_old, &a.share_young);
+        if (a.share_old > 16 || a.share_young < 1 || a.share_young >= a.share_old) a.share_old = a.share_young = 0;
+    }
     hipLaunchKernelGGL((gpv_sets_kernel<P, D, COV>), dim3(grid), dim3(W * 64), 0, stream, a);
     return hipGetLastError();
 }

@@ -292,3 +292,28 @@ def test_plain_c_caller_known_answer(tmp_path):
     import gpvecchia_amd  # noqa: F401
     r = subprocess.run([_build_c_caller(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0 and "known-answer test ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_r_layout_cache_sees_in_place_edits_and_holds_no_reference():
+    """api._r_layout_cached: the converted copies of the index arrays are reused only for the same objects with unchanged
+    content (an in-place edit between two U_NZentries calls must not be answered from the stale copy), and the cache keeps
+    the caller's arrays alive no longer than the caller does."""
+    import gc
+    import weakref
+    from gpvecchia_amd import api as A
+    rng = np.random.default_rng(0)
+    nn = rng.integers(0, 50, size=(200, 6)).astype(np.int32)
+    cd = rng.integers(-1, 2, size=(200, 6)).astype(np.int8)
+    a1, b1 = A._r_layout_cached(nn, cd)
+    a2, b2 = A._r_layout_cached(nn, cd)
+    assert a2 is a1 and b2 is b1                                        # hit: same objects, same content
+    nn[0, 0] += 1                                                       # first row is part of the fingerprint
+    a3, _ = A._r_layout_cached(nn, cd)
+    assert a3 is not a1 and a3[0, 0] == nn[0, 0]
+    nn[17, 3] += 1                                                      # 1200 entries: every entry is in the sample
+    a4, _ = A._r_layout_cached(nn, cd)
+    assert a4 is not a3 and a4[17, 3] == nn[17, 3]
+    w = weakref.ref(nn)
+    del nn, a1, a2, a3, a4
+    gc.collect()
+    assert w() is None                                                  # only weak references inside the cache

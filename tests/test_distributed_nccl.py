@@ -118,13 +118,13 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
 n, locs, z, revNN, revCond, cp, tau = _problem()
 sl = ShardedLikelihood(n, z, lambda a, b: G.Plan(locs, revNN, revCond, device=lr, row_begin=a, row_end=b))
 ll = sl.loglik("matern", cp, tau)
-print("RESULT " + json.dumps(dict(rank=dist.get_rank(), a=sl.row_begin, b=sl.row_end, ll=ll)), flush=True)
+print("RESULT " + json.dumps(dict(rank=dist.get_rank(), a=sl.row_begin, b=sl.row_end, ll=ll, route=sl.route)), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
-def test_sharded_likelihood_rccl_world2():
+def test_sharded_likelihood_rccl_world2(tmp_path):
     import json
     import torch
     import gpvecchia_amd as G
@@ -135,8 +135,7 @@ def test_sharded_likelihood_rccl_world2():
     ref.set_data(z)
     ref.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
     ll1 = G.loglik_z_from_sums(ref.sums(), n)
-    script = os.path.join(ROOT, "gpurun_out", "_nccl_worker.py")
-    os.makedirs(os.path.dirname(script), exist_ok=True)
+    script = str(tmp_path / "nccl_worker.py")
     open(script, "w").write(_WORKER.format(root=ROOT))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
@@ -145,5 +144,5 @@ def test_sharded_likelihood_rccl_world2():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = sorted((json.loads(l[7:]) for l in r.stdout.splitlines() if l.startswith("RESULT ")), key=lambda d: d["rank"])
     assert len(res) == 2 and (res[0]["a"], res[0]["b"], res[1]["b"]) == (0, n // 2, n)
-    assert res[0]["ll"] == res[1]["ll"]
+    assert res[0]["ll"] == res[1]["ll"] and res[0]["route"] == res[1]["route"]       # the ranks agreed on ONE route
     assert abs(res[0]["ll"] - ll1) <= 1e-12 * abs(ll1)
