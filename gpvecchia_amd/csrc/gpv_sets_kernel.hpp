@@ -282,7 +282,7 @@ constexpr int blocks_per_cu()
 {
     const int w = wpb<P, D, COV>();
     const int by_lds = (int)(163840 / (sizeof(SetsLds<P, D, COV>) * w));
-    const int cap = 8 / w;                          // 2 waves per SIMD
+    const int cap = (4 * Geo<P>::MINW) / w;         // Geo<P>::MINW waves per SIMD
     return by_lds < cap ? (by_lds < 1 ? 1 : by_lds) : cap;
 }
 // General-nu Matern: rows of the per-launch table of s^nu K_nu(s) e^s kept in LDS by every workgroup (a WINDOW of whole
