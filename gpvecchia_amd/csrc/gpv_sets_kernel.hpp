@@ -95,6 +95,9 @@
 #ifndef GPV_OPT_UNEVEN
 #define GPV_OPT_UNEVEN 1      // one workgroup per resident slot: the workgroups dispatched first take two tasks for every one of the
 #endif                        // workgroups dispatched second (the older wavefront of a SIMD is issued first: see the task loop)
+#ifndef GPV_OPT_PFOUT
+#define GPV_OPT_PFOUT 1       // modes that write per-set outputs: the set's output row (rowid) travels one task ahead with its indices,
+#endif                        // its compact-block offset from the middle of the previous sweep: no dependent loads in a task's epilogue
 #ifndef GPV_OPT_KARGS
 #define GPV_OPT_KARGS 1       // arguments used only in a task's epilogue / after the task loop are read from the kernarg segment THERE
 #endif                        // (scalar loads) instead of living in SGPRs through the loop: the compiler spilled them to VGPR lanes
@@ -773,16 +776,32 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
     // neighbour indices and cond flags are requested one task ahead: a task then starts with its (dependent) record gathers
     // instead of with two trips in a row, which two wavefronts per SIMD do not always hide
     int pidx[RPL], pcnd[RPL];
+    // Output addresses of a set (modes U / S and the a_k vector): rowid[k], and for the posterior pass cboff[rowid[k]], are two
+    // DEPENDENT loads.  Asked for in the epilogue, where they are needed, they cost every task two exposed trips to memory
+    // (the set kernel of --mode S ran 1.30 ms against 1.18 in mode L, and all but 0.02 ms of that WITHOUT the pass running in
+    // between: tools/sessions/r4_modeS.sh; SQ_WAIT_ANY +50 %).  Now the output row travels with the indices one task ahead and
+    // the block offset with the location records from the middle of the previous sweep.
+    const bool want_row = GPV_OPT_PFOUT != 0 && ((A.flags & (1 | kFlagFused)) != 0 || A.aout != nullptr);
+    const bool want_cb = GPV_OPT_PFOUT != 0 && (A.flags & kFlagFused) != 0;
+    typedef __attribute__((address_space(1))) const int32_t gl_ci32_t;
+    gl_ci32_t *cboff_pf = nullptr;                           // (fused: from the header in front of aout, once)
+    if (want_cb) {
+        typedef __attribute__((address_space(1))) const unsigned long long gl_cu64_t;
+        cboff_pf = reinterpret_cast<gl_ci32_t *>(((gl_cu64_t *)A.aout - 4)[1]);
+    }
+    int prow = 0, pcb = 0;
     auto load_ic = [&](const int64_t t) __attribute__((always_inline)) {
         const int64_t kk = t * SPW + sub;
         const bool on = lane_on && t < task_hi && kk < A.rows;
 #if GPV_OPT_KARGS
         KSetArgs *const Kg = kargs_now();
+        if (want_row) prow = ((gl_ci32_t *)Kg->rowid)[on ? kk : 0];
         typedef __attribute__((address_space(1))) const int32_t gl_ci32;
         typedef __attribute__((address_space(1))) const uint8_t gl_cu8;
         gl_ci32 *const nnp = (gl_ci32 *)Kg->nn;
         gl_cu8 *const cdp = (gl_cu8 *)Kg->cond;
 #else
+        if (want_row) prow = ((gl_ci32_t *)A.rowid)[on ? kk : 0];
         const int32_t *const nnp = A.nn;
         const uint8_t *const cdp = A.cond;
 #endif
@@ -859,6 +878,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             pr1[q].x = rb.x; pr1[q].y = rb.y;
             pnug[q] = (nugp != nullptr) ? nugp[at] : nugs;
         }
+        if (want_cb) pcb = cboff_pf[prow];                   // prow: the NEXT task's output row by now (or this one's, in the prologue)
     };
     if constexpr (PFREC) load_rec();
     int task_layer = 0;
@@ -871,6 +891,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         // out of the task loop (2P SGPRs -> SGPR spills through v_writelane/v_readlane inside the sweep)
         int i = i_const;
         asm volatile("" : "+v"(i));
+        const int row_out = prow;                             // this task's output row / block offset (the loads below replace them)
+        int cb_pf = pcb;
 #if GPV_OPT_PRIO
         // The two wavefronts that share a SIMD come from two workgroups; the issue arbiter prefers the OLDER wave on equal
         // priority, and this kernel is bound by VALU issue: measured (tools/wave_timeline.py, 125 000 rows, one workgroup per
@@ -971,6 +993,9 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         if (tr_t[1] == 0ull) tr_t[1] = wall_clock64();        // first task gathered (prologue + two trips to memory behind us)
         ++tr_tasks;
 #endif
+        if constexpr (!PFREC) {                               // (geometries whose records are fetched in the gather: the offset here)
+            if (want_cb) cb_pf = cboff_pf[row_out];
+        }
         load_ic(task_next);                                   // the next task's indices travel during this task
 
         // ---- covariance: every unordered pair once, circulant pairing ------------------
@@ -1396,7 +1421,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #endif
         if (A.flags & 1) {
             const int n0 = P - nmiss;
-            const int64_t kout = set_on ? (int64_t)rowid[k] : 0;       // row of Lentries this stored set belongs to
+            const int64_t kout = set_on ? (int64_t)(want_row ? row_out : rowid[k]) : 0;   // row of Lentries this stored set belongs to
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
                 if (set_on && row[q] < P) {
@@ -1420,7 +1445,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             Cout = reinterpret_cast<gl_v2d *>(hdr[0]);
             typedef __attribute__((address_space(1))) const int32_t gl_cint;
             const gl_cint *cboff = reinterpret_cast<const gl_cint *>(hdr[1]);
-            cb = set_on ? (int64_t)cboff[rowid[k]] : 0;
+            cb = set_on ? (int64_t)(want_cb ? cb_pf : cboff[rowid[k]]) : 0;
             const bool both = (A.flags & kFlagBoth) != 0;
 #pragma unroll
             for (int q = 0; q < RPL; ++q)
@@ -1447,7 +1472,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const bool good = set_on && !fail;
                 const double tau = nugraw[QO];
                 const double zk = zi[QO];
-                if (aout != nullptr && set_on && i == IO) aout[rowid[k]] = fail ? 0.0 : negmu * rs;
+                if (aout != nullptr && set_on && i == IO) aout[want_row ? row_out : rowid[k]] = fail ? 0.0 : negmu * rs;
                 if (fused && set_on && i == IO) Cout[cb] = v2d_out{fail ? 0.0 : negmu * rs, 0.0};
                 if (A.flags & 2) {
                     const double tv = tau + vlast;
