@@ -1444,3 +1444,37 @@ def test_cond_y_denominator_on_the_device_with_bounded_fill():
     vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="y")
     ll_ref = R.vecchia_likelihood(z, vb, [1.0, 0.1, 1.5], 0.1)
     assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
+
+
+def test_evaluation_inside_a_stream_capture_replays_correctly():
+    """gpv_plan_eval enqueued while the caller's stream is being captured into a graph: the sequence-number hand-off would be
+    frozen into the graph (every replay publishing the same number), so the evaluation must fall back to "wait for the
+    stream" there; every replay leaves the right totals."""
+    G = _need_gpu()
+    import torch
+    from gpvecchia_amd import specify as S
+    rng = np.random.default_rng(77)
+    n, m = 30_000, 20
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    NN = S.find_ordered_nn_gpu(locs, m)
+    revNN = NN[:, ::-1].copy()
+    revCond = np.where(revNN != 0, 0, -1).astype(np.int8); revCond[:, -1] = 1
+    cp, tau = [1.2, 0.03, 1.5], 0.1
+    ref = G.Plan(locs, revNN, revCond); ref.set_data(z)
+    ref.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z)
+    want = ref.sums().copy()
+    plan = G.Plan(locs, revNN, revCond); plan.set_data(z)
+    plan.eval("matern", [0.7, 0.05, 0.5], 0.3, G.GPV_WANT_LOGLIK_Z)       # other totals in the buffers first
+    other = plan.sums().copy()
+    assert not np.array_equal(other, want)
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z, stream=torch.cuda.current_stream().cuda_stream)
+    for rep in range(3):
+        plan.eval("matern", [0.7, 0.05, 0.5], 0.3, G.GPV_WANT_LOGLIK_Z)   # an ordinary evaluation in between: other totals again
+        assert np.array_equal(plan.sums(), other)
+        g.replay()
+        torch.cuda.synchronize()
+        # (the replay ran on torch's stream, which the plan knows nothing about: the totals are read after the device is idle)
+        assert np.array_equal(plan.sums(), want), rep
