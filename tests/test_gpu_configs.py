@@ -429,3 +429,60 @@ def test_full_size_maxmin_mode_L_n1e6_m30():
     ll = G.loglik_z_from_sums(s, n)
     assert abs(ll - ll_ref) <= LL_RTOL * abs(ll_ref)
     assert abs(G.vecchia_likelihood(z, va, cp, tau) - ll_ref) <= LL_RTOL * abs(ll_ref)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# ordered nearest neighbours through the grid (round 4, csrc/gpv_nn.hip): bit-exact with the definition
+# ----------------------------------------------------------------------------------------------------------------
+def _nn_definition_rows(locs, m, rows):
+    """The definition, row by row in NumPy: sqrt of the left-to-right sum of squared differences, ties -> lower index."""
+    out = np.zeros((len(rows), m + 1), dtype=np.int32)
+    for t, k in enumerate(rows):
+        ssq = np.zeros(k + 1)
+        for c in range(locs.shape[1]):
+            df = locs[k, c] - locs[: k + 1, c]
+            ssq = ssq + df * df
+        d = np.sqrt(ssq)
+        o = np.lexsort((np.arange(k + 1), d))[: min(m + 1, k + 1)]
+        out[t, : len(o)] = o + 1
+    return out
+
+
+@pytest.mark.parametrize("case", ["uniform2d", "uniform3d", "line1d", "lattice_ties", "duplicates", "clustered", "flat_dimension"])
+def test_grid_nn_search_is_bit_exact(case):
+    """Rows from 4096 on of problems in one to three dimensions take their candidates from a uniform grid
+    (gpv_nn_grid_kernel) instead of all predecessors.  Same arrays, bit for bit, as the definition: on sampled rows against
+    a NumPy restatement, on all rows against the host search (cKDTree with exact re-ranking), including a regular lattice
+    (every distance tied many times over), exact duplicates, strongly clustered points and a dimension without extent."""
+    G = _need_gpu()
+    from gpvecchia_amd import specify as S
+    rng = np.random.default_rng(99)
+    m = 30
+    if case == "uniform2d":
+        locs = rng.random((60_000, 2))
+    elif case == "uniform3d":
+        locs = rng.random((40_000, 3)); m = 20
+    elif case == "line1d":
+        locs = rng.random((30_000, 1)); m = 10
+    elif case == "lattice_ties":
+        gx, gy = np.meshgrid(np.arange(160) / 160.0, np.arange(100) / 100.0, indexing="ij")
+        locs = np.stack([gx.ravel(), gy.ravel()], axis=1)[rng.permutation(16_000)]; m = 12
+    elif case == "duplicates":
+        locs = rng.random((20_000, 2))
+        dup = rng.choice(np.arange(1, 20_000), 3000, replace=False)
+        locs[dup] = locs[dup - 1]
+    elif case == "clustered":
+        centres = rng.random((40, 2))
+        locs = centres[rng.integers(0, 40, 50_000)] + 1e-3 * rng.standard_normal((50_000, 2)); m = 25
+    else:
+        locs = np.stack([rng.random(20_000), np.full(20_000, 0.25)], axis=1); m = 8
+    n = locs.shape[0]
+    NN = S.find_ordered_nn_gpu(locs, m)
+    rows = np.concatenate([[0, 1, m, m + 1, 4095, 4096, 4097, n - 1], rng.integers(4096, n, 60)])
+    assert np.array_equal(NN[rows], _nn_definition_rows(locs, m, rows))
+    if case not in ("lattice_ties", "duplicates"):                       # (the host search re-ranks ties itself; keep it to the tie-free cases)
+        assert np.array_equal(NN, S.find_ordered_nn(locs, m))
+    # a row shard (what one rank of a multi-GPU job asks for) equals the same rows of the full search
+    a, b = n // 3, n // 3 + 5000
+    sh = S.find_ordered_nn_gpu(locs, m, rows=(a, b))
+    assert np.array_equal(sh[a:b], NN[a:b]) and not sh[:a].any() and not sh[b:].any()
