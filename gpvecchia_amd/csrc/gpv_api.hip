@@ -776,7 +776,11 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     hipStream_t st = stream_v ? (hipStream_t)stream_v : pl->stream;
     // the plan's buffers (nuggets, partial sums, U entries, posterior blocks) are reused by every evaluation: one that
     // moves to ANOTHER stream first waits for the previous stream, evaluations on one stream are ordered by it
-    if (pl->last_stream && pl->last_stream != st) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    // (not while `st` is being captured into a graph: a host wait is illegal there, and the caller who captures owns the
+    // ordering against the plan's earlier evaluations)
+    hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap0) != hipSuccess) { (void)hipGetLastError(); cap0 = hipStreamCaptureStatusNone; }
+    if (pl->last_stream && pl->last_stream != st && cap0 == hipStreamCaptureStatusNone) GPV_HIP(hipStreamSynchronize(pl->last_stream));
     if ((flags & GPV_WANT_U) && !pl->d_L) {
         GPV_HIP(hipMalloc((void **)&pl->d_L, sizeof(double) * (size_t)(pl->rows > 0 ? pl->rows : 1) * pl->P));
     }

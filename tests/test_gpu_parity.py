@@ -1469,6 +1469,7 @@ def test_evaluation_inside_a_stream_capture_replays_correctly():
     assert not np.array_equal(other, want)
     side = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()                                             # (the capturing caller owns the ordering against earlier evaluations)
     with torch.cuda.graph(g, stream=side):
         plan.eval("matern", cp, tau, G.GPV_WANT_LOGLIK_Z, stream=torch.cuda.current_stream().cuda_stream)
     for rep in range(3):
