@@ -89,9 +89,6 @@
 #ifndef GPV_OPT_GEN_NOLIVE
 #define GPV_OPT_GEN_NOLIVE 1  // general nu: no select on dist == 0 in the rounds; coincident points have s below every table segment,
 #endif                        // are flagged like any pair outside the table and get sigma^2 from the out-of-line pass
-#ifndef GPV_OPT_PRIO
-#define GPV_OPT_PRIO 0        // a pseudo-random wave priority (s_setprio 0..3) per task: measured, superseded by GPV_OPT_UNEVEN
-#endif
 #ifndef GPV_OPT_UNEVEN
 #define GPV_OPT_UNEVEN 1      // one workgroup per resident slot: the workgroups dispatched first take two tasks for every one of the
 #endif                        // workgroups dispatched second (the older wavefront of a SIMD is issued first: see the task loop)
@@ -893,21 +890,6 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         asm volatile("" : "+v"(i));
         const int row_out = prow;                             // this task's output row / block offset (the loads below replace them)
         int cb_pf = pcb;
-#if GPV_OPT_PRIO
-        // The two wavefronts that share a SIMD come from two workgroups; the issue arbiter prefers the OLDER wave on equal
-        // priority, and this kernel is bound by VALU issue: measured (tools/wave_timeline.py, 125 000 rows, one workgroup per
-        // slot) the older wave runs 7.1 us per task, the younger 13.8, the older one is done after 113 of 170 us and the
-        // younger finishes ALONE at 6.8 us per task where the pair managed 4.7: a third of the kernel at 3/4 of the SIMD's
-        // throughput.  A pseudo-random priority per task (a hash of the task number: no two partners follow the same sequence)
-        // makes either wave the preferred one about as often, both progress at about the same rate and leave together.
-        // Which task a wave runs, and in which order its sums accumulate, does not change: results are bit for bit the same.
-        switch (((unsigned)task * 2654435761u) >> 30) {
-            case 0: __builtin_amdgcn_s_setprio(0); break;
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            default: __builtin_amdgcn_s_setprio(3); break;
-        }
-#endif
 
         // ---- gather: indices, cond flags, coordinates, nugget, data -------------------
         int row[RPL], idx[RPL], cndraw[RPL], wslot[RPL];     // cndraw: the cond byte as stored (flag in bit 0, block position above it)

@@ -241,3 +241,33 @@ def test_zy_mean_runs_on_the_device_and_wrappers():
     np.testing.assert_allclose(lpred["mu_pred"], direct["mu_pred"], rtol=0, atol=1e-12)
     np.testing.assert_allclose(lpred["data_pred"], np.exp(direct["mu_pred"]), rtol=1e-12)
     assert np.corrcoef(lpred["mu_pred"], np.sin(5 * lp[:, 0]) * np.cos(4 * lp[:, 1]))[0, 1] > 0.8
+
+
+def test_set_observed_argument_rules():
+    """gpv_plan_set_observed: a constant nugget cannot say "no observation here", so the posterior pass refuses it while
+    unobserved locations are set (GPV_ERR_BAD_ARG); an all-TRUE mask or NULL puts the plan back to "all observed"."""
+    G = _need_gpu()
+    rng = np.random.default_rng(8)
+    n, n_p, m = 300, 100, 6
+    locs, lp = rng.random((n, 1)), rng.random((n_p, 1))
+    va = G.vecchia_specify(locs, m, locs_pred=lp)
+    from gpvecchia_amd import api as A
+    plan = A._plan_for(va)
+    assert plan.build_posterior_fill() is not None
+    nrows = va["locsord"].shape[0]
+    z = np.zeros(nrows); z[np.asarray(va["obs"], bool)] = rng.standard_normal(n)
+    plan.set_data(z)
+    plan.set_observed(va["obs"])
+    with pytest.raises(G.GpvError) as e:
+        plan.eval("matern", [1.0, 0.05, 0.5], 0.1, G.GPV_WANT_MEAN)
+    assert e.value.status == 2
+    nug = np.where(np.asarray(va["obs"], bool), 0.1, 0.0)
+    plan.eval("matern", [1.0, 0.05, 0.5], nug, G.GPV_WANT_MEAN)
+    mu_masked = plan.posterior_mean().copy()
+    assert np.isfinite(mu_masked).all()
+    plan.set_observed(None)                                            # all observed again: the zero nuggets now mean 1/0 in W
+    plan.eval("matern", [1.0, 0.05, 0.5], 0.1, G.GPV_WANT_MEAN)
+    mu_all = plan.posterior_mean()
+    assert np.isfinite(mu_all).all() and not np.allclose(mu_all, mu_masked)
+    with pytest.raises(ValueError):
+        plan.set_observed(np.ones(3, bool))
