@@ -176,22 +176,43 @@ class Comm:
     """gpv_comm: an RCCL communicator owned by the library (one process per GPU).  `exchange(id_bytes_or_None) -> id_bytes`
     carries rank 0's 128-byte id to the other ranks (from_torch() does it over an initialised torch.distributed group)."""
 
-    def __init__(self, device, rank, world, exchange):
-        ident = C.create_string_buffer(128)
-        st0 = L.lib().gpv_comm_unique_id(ident) if rank == 0 else 0
-        # rank 0 ALWAYS takes part in the exchange: if it could not make the id it hands out an empty one and every rank
-        # raises here, instead of rank 0 raising alone while the others wait for a broadcast that never comes
-        raw = exchange((bytes(ident.raw) if st0 == 0 else b"") if rank == 0 else None)
-        if rank == 0:
-            L.check(st0, "gpv_comm_unique_id")
-        if raw == b"":
-            raise RuntimeError("Comm: rank 0 could not produce the communicator id (no RCCL to bind?)")
+    def __init__(self, device, rank, world, exchange=None, ident=None):
+        """exchange(id_bytes_or_None) -> id_bytes carries rank 0's id to the others; or `ident`: the 128 bytes every rank
+        already holds (Comm.exchange_id in a first step: negotiate_comm does the exchange on the caller's thread and only the
+        collective gpv_comm_create on a helper thread)."""
+        raw = ident if ident is not None else Comm.exchange_id(rank, exchange)
         if not isinstance(raw, (bytes, bytearray)) or len(raw) != 128:
             raise ValueError("Comm: the exchange must hand every rank the 128 bytes of rank 0")
         ident = C.create_string_buffer(bytes(raw), 128)
         self._h = C.c_void_p()
         self.device, self.rank, self.world = int(device), int(rank), int(world)
         L.check(L.lib().gpv_comm_create(C.byref(self._h), self.device, self.rank, self.world, ident), "gpv_comm_create")
+
+    @staticmethod
+    def exchange_id(rank, exchange):
+        """Rank 0 makes the communicator id and `exchange` hands it to every rank.  Rank 0 ALWAYS takes part in the exchange:
+        if it could not make the id it hands out an empty one and every rank raises here, instead of rank 0 raising alone
+        while the others wait for a broadcast that never comes."""
+        ident = C.create_string_buffer(128)
+        st0 = L.lib().gpv_comm_unique_id(ident) if rank == 0 else 0
+        raw = exchange((bytes(ident.raw) if st0 == 0 else b"") if rank == 0 else None)
+        if rank == 0:
+            L.check(st0, "gpv_comm_unique_id")
+        if raw == b"":
+            raise RuntimeError("Comm: rank 0 could not produce the communicator id (no RCCL to bind?)")
+        return raw
+
+    @staticmethod
+    def torch_exchange(group=None):
+        """The exchange over an initialised torch.distributed group (call it on the thread that owns the rank's GPU: with
+        the nccl backend the broadcast moves through torch.cuda.current_device() of the CALLING thread)."""
+        import torch.distributed as dist
+
+        def exchange(mine):
+            box = [mine]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            return box[0]
+        return exchange
 
     @classmethod
     def from_torch(cls, device, group=None):

@@ -70,11 +70,23 @@ def negotiate_comm(device, group=None, timeout_s=120.0, log=None):
         ver, _ = 0, say(f"gpv_rccl_version failed: {e!r}")
     if _agree_min(1 if (ver >= 2000 and not forced) else 0, group, device) == 0:
         return None, ("GPV_TORCH_ALLREDUCE=1" if forced else f"RCCL not bound on every rank (this rank: version {ver})")
+    import torch.distributed as dist
     box = {}
+    # the id travels over the torch group on THIS thread (a helper thread's current CUDA device is device 0 on every rank:
+    # an nccl broadcast issued from it would run on the wrong GPU for every rank but the first); only the collective
+    # gpv_comm_create, which binds its device itself, runs on the helper thread and can be timed out
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ident = None
+    try:
+        ident = Comm.exchange_id(rank, Comm.torch_exchange(group))
+    except Exception as e:
+        say(f"communicator id not exchanged: {e!r}")
+    if _agree_min(1 if ident is not None else 0, group, device) == 0:
+        return None, "the communicator id could not be made or exchanged"
 
     def work():
         try:
-            box["comm"] = Comm.from_torch(device, group)
+            box["comm"] = Comm(device, rank, world, ident=ident)
         except Exception as e:
             box["err"] = e
 
