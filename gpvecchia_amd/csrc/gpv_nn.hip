@@ -248,20 +248,34 @@ extern "C" int gpv_find_ordered_nn(int device, const double *locs, int64_t n, in
             ext[t] = hi - lo;
             finite = finite && (lo - lo == 0.0) && (ext[t] - ext[t] == 0.0);
         }
+        // cell edge h: ~3 points per cell over the dimensions that get more than one cell; a dimension thinner than h is
+        // left out (one cell across it) and h recomputed from the others
+        bool split[3] = {false, false, false};
         int live = 0;
-        for (int t = 0; t < dim; ++t) if (ext[t] > 0.0) { vol *= ext[t]; ++live; }
+        double h = 0.0;
+        for (int t = 0; t < dim; ++t) split[t] = ext[t] > 0.0;
+        for (int pass = 0; pass < 4; ++pass) {
+            vol = 1.0; live = 0;
+            for (int t = 0; t < dim; ++t) if (split[t]) { vol *= ext[t]; ++live; }
+            if (live == 0) break;
+            h = std::pow(vol * 3.0 / (double)n, 1.0 / live);
+            bool changed = false;
+            for (int t = 0; t < dim; ++t) if (split[t] && ext[t] < h) { split[t] = false; changed = true; }
+            if (!changed) break;
+        }
+        for (int t = 0; t < dim; ++t) if (!split[t]) ext[t] = (ext[t] > 0.0) ? ext[t] : 0.0;
         if (!finite || live == 0) {
             // (NaN / Inf coordinates or all points identical: the brute-force kernel defines the result)
         } else {
-            const double h = std::pow(vol * 3.0 / (double)n, 1.0 / live);        // ~3 points per cell
             G.hmin = __builtin_inf();
             int64_t ncell = 1;
             for (int t = 0; t < dim; ++t) {
-                int g = ext[t] > 0.0 ? (int)(ext[t] / h) : 1;
+                int g = split[t] ? (int)(ext[t] / h) : 1;
                 g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
                 G.g[t] = g;
                 G.inv[t] = ext[t] > 0.0 ? (double)g / ext[t] : 0.0;
-                if (ext[t] > 0.0) { const double e = ext[t] / g; G.hmin = e < G.hmin ? e : G.hmin; }
+                // (a dimension with ONE cell never separates a shell from the query: only the others bound the distance)
+                if (g > 1) { const double e = ext[t] / g; G.hmin = e < G.hmin ? e : G.hmin; }
                 ncell *= g;
             }
             // counting sort by cell, stable: ascending index inside every cell

@@ -448,7 +448,8 @@ def _nn_definition_rows(locs, m, rows):
     return out
 
 
-@pytest.mark.parametrize("case", ["uniform2d", "uniform3d", "line1d", "lattice_ties", "duplicates", "clustered", "flat_dimension"])
+@pytest.mark.parametrize("case", ["uniform2d", "uniform3d", "line1d", "lattice_ties", "duplicates", "clustered", "flat_dimension",
+                                  "thin_slab"])
 def test_grid_nn_search_is_bit_exact(case):
     """Rows from 4096 on of problems in one to three dimensions take their candidates from a uniform grid
     (gpv_nn_grid_kernel) instead of all predecessors.  Same arrays, bit for bit, as the definition: on sampled rows against
@@ -474,6 +475,8 @@ def test_grid_nn_search_is_bit_exact(case):
     elif case == "clustered":
         centres = rng.random((40, 2))
         locs = centres[rng.integers(0, 40, 50_000)] + 1e-3 * rng.standard_normal((50_000, 2)); m = 25
+    elif case == "thin_slab":                                           # an extent 1e-9 of the others: one cell across it
+        locs = rng.random((30_000, 3)) * np.array([1.0, 1.0, 1e-9]); m = 15
     else:
         locs = np.stack([rng.random(20_000), np.full(20_000, 0.25)], axis=1); m = 8
     n = locs.shape[0]
