@@ -357,6 +357,8 @@ struct gpv_plan {
     int32_t *d_order2 = nullptr, *d_levptr2 = nullptr;
     int4 *d_meanrec = nullptr;                       // mean sweep: one record per column in schedule order
     double *d_toppart = nullptr;                     // [top_K][66] partial sums of the top block's columns
+    int2 *d_topinfo = nullptr;                       // [top_K] {column, offset of its block in C}
+    uint8_t *d_toprows = nullptr;                    // [top_K][64] index inside the block of each entry's row
     int top_K = 0;                                   // columns 0 .. top_K-1 are kept out of the schedule (gpv_posterior_ext.h)
     int mean_head_levels = 0;                        // leading levels of the mean sweep run by one workgroup
     double *d_u = nullptr, *d_mu = nullptr;
@@ -435,7 +437,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec_base, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket,
-                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec, pl->d_obs};
+                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec, pl->d_obs, pl->d_topinfo, pl->d_toprows};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -983,7 +985,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                 e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0,
                                            lv < pl->lev_lpc.size() ? pl->lev_lpc[lv] : 64, st);
             if (e == hipSuccess && pl->top_K > 0)
-                e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, st);
+                e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, pl->d_topinfo, pl->d_toprows, st);
             if (e == hipSuccess)
                 e = launch_sum_pair(pl->d_rdiag, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, mirror, st);
             if (want_mean) {
@@ -1311,15 +1313,15 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
             }
         });
     }
-    // the dense top block (gpv_posterior_ext.h): the first K columns of the ordering stay out of the schedule
-    // (GPV_POST_TOP=0: all columns are scheduled)
-    static const bool no_top = getenv("GPV_POST_TOP") != nullptr && atoi(getenv("GPV_POST_TOP")) == 0;
-    const int64_t K = no_top ? 0 : std::min<int64_t>(n, kTopMax);
-    pl->top_K = (int)K;
-    // level of column k >= K = 1 + max level of the columns c > k that contain row k
+    // the dense top block (gpv_posterior_ext.h): the first columns of the ordering stay out of the schedule
+    // (GPV_POST_TOP=0: all columns are scheduled; GPV_POST_TOP=64: the one-block form only)
+    static const int top_env = getenv("GPV_POST_TOP") != nullptr ? atoi(getenv("GPV_POST_TOP")) : kTopMax;
+    const bool no_top = top_env <= 0;
+    const int64_t K0 = no_top ? 0 : std::min<int64_t>(n, kTopBlock);
+    // level of column k >= K0 = 1 + max level of the columns c > k that contain row k
     std::vector<int32_t> lev((size_t)n, 0);
     int32_t maxlev = -1;
-    for (int64_t k = n - 1; k >= K; --k) {
+    for (int64_t k = n - 1; k >= K0; --k) {
         int32_t l = 0;
         for (int32_t q = rowptr[(size_t)k]; q < rowptr[(size_t)k + 1]; ++q) {
             const int32_t c = rcol[(size_t)q];
@@ -1328,12 +1330,33 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         lev[(size_t)k] = l;
         if (l > maxlev) maxlev = l;
     }
+    // two-block form: the highest levels, a few columns each and one launch apiece, join the block while it has room.  A row
+    // i of a column k waits for k (level(i) > level(k)), so with a column all its rows are taken, and nothing below waits for them.
+    std::vector<int32_t> topcols;
+    std::vector<uint8_t> in_top((size_t)n, 0);
+    for (int64_t k = 0; k < K0; ++k) { topcols.push_back((int32_t)k); in_top[(size_t)k] = 1; }
+    if (!no_top && top_env > kTopBlock && maxlev >= 0) {
+        std::vector<int64_t> width((size_t)maxlev + 1, 0);
+        for (int64_t k = K0; k < n; ++k) width[(size_t)lev[(size_t)k]]++;
+        int64_t room = kTopMax - K0;
+        int32_t L = maxlev + 1;
+        while (L > 0 && width[(size_t)L - 1] <= room) { room -= width[(size_t)L - 1]; --L; }
+        if (L <= maxlev) {
+            for (int64_t k = K0; k < n; ++k)
+                if (lev[(size_t)k] >= L) { topcols.push_back((int32_t)k); in_top[(size_t)k] = 1; }
+            maxlev = L - 1;
+        }
+    }
+    const int64_t K = (int64_t)topcols.size();
+    pl->top_K = (int)K;
     pl->levptr.assign((size_t)(maxlev + 2), 0);
-    for (int64_t k = K; k < n; ++k) pl->levptr[(size_t)lev[(size_t)k] + 1]++;
+    for (int64_t k = K0; k < n; ++k)
+        if (!in_top[(size_t)k]) pl->levptr[(size_t)lev[(size_t)k] + 1]++;
     for (int32_t l = 0; l <= maxlev; ++l) pl->levptr[(size_t)l + 1] += pl->levptr[(size_t)l];
     std::vector<int32_t> pos(pl->levptr.begin(), pl->levptr.end() - 1), order((size_t)n);
-    for (int64_t k = n - 1; k >= K; --k) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
-    for (int64_t k = 0; k < K; ++k) order[(size_t)(n - K + k)] = (int32_t)k;      // the top block's records: after the schedule
+    for (int64_t k = n - 1; k >= K0; --k)
+        if (!in_top[(size_t)k]) order[(size_t)pos[(size_t)lev[(size_t)k]]++] = (int32_t)k;
+    for (int64_t j = 0; j < K; ++j) order[(size_t)(n - K + j)] = topcols[(size_t)j];   // the top block's records: after the schedule
     // The compact blocks are laid out in the Morton order of the locations (the internal order of the plan's location
     // records): a column gathers from the columns of the points that condition on it, its spatial neighbours, whose blocks
     // then share cache lines and L2 sets instead of being scattered by a maxmin ordering.
@@ -1387,22 +1410,32 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         const int32_t k = order[(size_t)i];
         const int32_t b0 = colptr[(size_t)k], cn = colptr[(size_t)k + 1] - b0;
         colrec[2 * (size_t)i] = make_int4(k, cboff[(size_t)k], cn, rowptr[(size_t)k]);
-        // .y: end of the row-list entries whose column lies in the top block (row lists ascend: a prefix)
-        int32_t qt = rowptr[(size_t)k];
-        if ((int64_t)k < K)
-            while (qt < rowptr[(size_t)k + 1] && (int64_t)rcol[(size_t)qt] < K) ++qt;
-        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], qt, 0, 0);
+        colrec[2 * (size_t)i + 1] = make_int4(rowptr[(size_t)k + 1], 0, 0, 0);
     }
     std::vector<int32_t> ccol(nnz);
     for (int64_t c = 0; c < n; ++c) {
         const int32_t b0 = colptr[(size_t)c], cn = colptr[(size_t)c + 1] - b0;
         for (int32_t e = 0; e < cn; ++e) {
             const size_t q = (size_t)qof[(size_t)(b0 + e)];               // the pair (row crow[b0+e], column c)
-            rowrec[q] = make_int4(cboff[(size_t)c], tptr[q], e | ((e + 1 < cn ? e + 1 : 0) << 8), 0);
+            rowrec[q] = make_int4(cboff[(size_t)c], tptr[q], e | ((e + 1 < cn ? e + 1 : 0) << 8), (int)in_top[(size_t)c]);   // .w: column c is in the top block
             ccol[(size_t)(b0 + e)] = (int32_t)c;
         }
     }
 
+    // the top block's own tables: where each of its columns lives, and the index inside the block of each entry's row
+    std::vector<int2> topinfo((size_t)K);
+    std::vector<uint8_t> toprows((size_t)K * kTopBlock, (uint8_t)0xFF);
+    for (int64_t j = 0; j < K; ++j) {
+        const int32_t k = topcols[(size_t)j];
+        topinfo[(size_t)j] = make_int2(k, cboff[(size_t)k]);
+        const int32_t b0 = colptr[(size_t)k], cn = colptr[(size_t)k + 1] - b0;
+        if (cn > kTopBlock) return GPV_ERR_UNSUPPORTED_M;
+        for (int32_t e = 0; e < cn; ++e) {
+            const auto it = std::lower_bound(topcols.begin(), topcols.end(), crow[(size_t)(b0 + e)]);
+            if (it == topcols.end() || *it != crow[(size_t)(b0 + e)]) return GPV_ERR_STATE;     // (cannot happen: see above)
+            toprows[(size_t)j * kTopBlock + (size_t)e] = (uint8_t)(it - topcols.begin());
+        }
+    }
     // second schedule for the posterior mean (R^T u = t): column k waits for the rows i < k it contains
     std::vector<int32_t> lev2((size_t)n, 0);
     int32_t maxlev2 = 0;
@@ -1486,6 +1519,8 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     if ((rc = up((void **)&pl->d_levptr2, pl->levptr2.data(), pl->levptr2.size() * 4)) != GPV_OK) return rc;
     if (pl->d_toppart) { (void)hipFree(pl->d_toppart); pl->d_toppart = nullptr; }
     if (pl->top_K > 0) GPV_HIP(hipMalloc((void **)&pl->d_toppart, sizeof(double) * 66 * (size_t)pl->top_K));
+    if ((rc = up((void **)&pl->d_topinfo, topinfo.data(), topinfo.size() * sizeof(int2))) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_toprows, toprows.data(), toprows.size())) != GPV_OK) return rc;
     pl->mean_head_levels = 0;
     static const bool no_head = getenv("GPV_NO_MEAN_HEAD") != nullptr;
     while (!no_head && (size_t)pl->mean_head_levels + 1 < pl->levptr2.size() &&
@@ -1508,7 +1543,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     if (!pl->d_rdiag) GPV_HIP(hipMalloc((void **)&pl->d_rdiag, nd));
     if (!pl->d_u) GPV_HIP(hipMalloc((void **)&pl->d_u, nd));
     if (!pl->d_mu) GPV_HIP(hipMalloc((void **)&pl->d_mu, nd));
-    if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 512));
+    if (!pl->d_post_part) GPV_HIP(hipMalloc((void **)&pl->d_post_part, sizeof(double) * 2048));       // launch_sum_pair: 2 x 1024
     if (!pl->d_L && !pl->post_fused) GPV_HIP(hipMalloc((void **)&pl->d_L, nd * pl->P));   // (fused: only when the caller wants U)
     pl->have_post = true;
     return GPV_OK;

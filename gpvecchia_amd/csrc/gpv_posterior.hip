@@ -85,8 +85,8 @@ __device__ __forceinline__ double post_rcp(const double x)
 }
 
 // One column of the factor.  c0, c1: its column record.
-// MODE 1 (the columns of the dense top block, gpv_posterior_top_kernel): no epilogue, the partial sums (64 rows, z2, s) go to
-// tpart; the first entries of the row list, up to c1.y, are the other top columns, whose R and t do not exist yet: their
+// MODE 1 (the columns of the dense top block, gpv_posterior_top_kernel): no pivot, the column's sums (64 rows, z2, s) go to
+// tpart; the row-list entries flagged in rowrec.w are the other top columns, whose R and t do not exist yet: their
 // B B^T terms and B a are taken here, their R R^T terms and R t are the top kernel's part.
 // ZST: the two scalar sums of a column (z2 = sum_c B_kc a_c and s = sum_c R_kc t_c) ride in the LDS tile as two more rows
 // (cnt and cnt + 1) and are totalled by the row-sum step that runs anyway, instead of two 6-step cross-lane butterflies
@@ -140,7 +140,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         if (act) {
             Bk = own.x;
             if (!ZST && sub == 0) z2 = __builtin_fma(Bk, head.x, z2);
-            if (ne > 0 && !(MODE == 1 && q < c1.y)) {
+            if (ne > 0 && !(MODE == 1 && rr.w != 0)) {
                 Rk = own.y;
                 rk_on = true;
                 if (!ZST && sub == 0) s = __builtin_fma(Rk, head.y, s);
@@ -221,13 +221,13 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         z2 = __builtin_fma(dk, ak_own, __shfl(acc, cnt, 64));
         s = __shfl(acc, cnt + 1, 64);
     }
-    if constexpr (MODE == 1) {
-        tpart[lane] = acc;
-        if (lane == 0) { tpart[64] = z2; tpart[65] = s; }
-        return;
-    }
     if (lane < cnt) acc = __builtin_fma(bk_own, dk, acc);             // c == k term: B_ik d_k
     const double itau = post_rcp(tau);
+    if constexpr (MODE == 1) {                           // the block's entry S_ik (1/tau on the diagonal), z2 with the data term, s
+        tpart[lane] = (lane == cnt - 1) ? acc + itau : acc;
+        if (lane == 0) { tpart[64] = __builtin_fma(-zk, itau, z2); tpart[65] = s; }
+        return;
+    }
     const double accd = __shfl(acc, cnt - 1, 64) + itau;
     double rkk, rinv;
     top_pivot(accd, rkk, rinv);
@@ -442,6 +442,10 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
 //       k < c (column c of R travels to all lanes as LDS broadcast reads) and s_i += R_ic t_c.
 // The other waves of the workgroup only help to load the block through LDS and to store the result.
 constexpr int kTop = 64;
+__device__ __forceinline__ void top_wg_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __device__ __forceinline__ double readlane_f64(double v, int l)
 {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)__double2loint(v), l);
@@ -486,7 +490,8 @@ struct TopStep {
     }
 };
 constexpr int kTopWaves = 4, kTopJ = kTop / kTopWaves;   // 4 waves = one per SIMD: the factorising wave may use the whole VGPR file
-__global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const PostArgs A, const double *tpart, const int K)
+__global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const PostArgs A, const double *tpart, const int K,
+                                                                           const int2 *topinfo, const uint8_t *toprows)
 {
     __shared__ double Sl[kTop][kTop + 1];            // the block by (row, column)
     __shared__ unsigned char Pl[kTop][kTop];         // 1: (row, column) on the pattern
@@ -499,44 +504,28 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
     }
     if (wave == 0) { zl[lane] = 0.0; sl[lane] = 0.0; }
     __syncthreads();
-    // wave w loads the columns w, w + 4, ..: lane = entry of the column.  Loads first, all of them in flight together
-    int cpj[kTopJ], cntj[kTopJ], rowi[kTopJ], cbj[kTopJ];
+    // wave w loads the columns w, w + 4, ..: lane = entry of the column; one trip, all loads in flight together
+    int rowi[kTopJ];
+    int2 inf[kTopJ];
+    double vp[kTopJ], vz[kTopJ];
 #pragma unroll
     for (int j = 0; j < kTopJ; ++j) {
         const int k = wave + kTopWaves * j;
-        cpj[j] = (k < K) ? A.colptr[k] : 0;
-        cntj[j] = (k < K) ? A.colptr[k + 1] - cpj[j] : 0;
-        cbj[j] = (k < K) ? A.cboff[k] : 0;
-    }
-    double vb[kTopJ], vd[kTopJ], vp[kTopJ], vt[kTopJ], vz[kTopJ], vpz[kTopJ], vps[kTopJ];
-#pragma unroll
-    for (int j = 0; j < kTopJ; ++j) {
-        const int k = wave + kTopWaves * j;
-        const bool own = lane < cntj[j];
-        const double2 *Ck = A.C + cbj[j];
-        rowi[j] = own ? A.crow[cpj[j] + lane] : -1;
-        vb[j] = own ? Ck[1 + lane].x : 0.0;
-        vd[j] = own ? Ck[cntj[j]].x : 0.0;
-        vp[j] = own ? tpart[66 * (size_t)k + lane] : 0.0;
-        vt[j] = own ? ((A.nuggets != nullptr) ? A.nuggets[k] : A.nug_cell[0]) : 1.0;
-        const bool last = own && lane == cntj[j] - 1;
-        vz[j] = last ? A.z[k] : 0.0;
-        vpz[j] = last ? tpart[66 * (size_t)k + 64] : 0.0;
-        vps[j] = last ? tpart[66 * (size_t)k + 65] : 0.0;
+        const bool in = k < K;
+        rowi[j] = in ? (int)toprows[kTop * k + lane] : 0xFF;
+        vp[j] = in ? tpart[66 * (size_t)k + lane] : 0.0;
+        vz[j] = (in && lane < 2) ? tpart[66 * (size_t)k + 64 + lane] : 0.0;
+        inf[j] = in ? topinfo[k] : make_int2(0, 0);
     }
 #pragma unroll
     for (int j = 0; j < kTopJ; ++j) {
         const int k = wave + kTopWaves * j;
-        if (rowi[j] >= 0) {
-            double v = __builtin_fma(vb[j], vd[j], vp[j]);                 // c == k term: B_ik d_k
-            if (lane == cntj[j] - 1) {
-                v += 1.0 / vt[j];
-                zl[k] = vpz[j] - vz[j] / vt[j];
-                sl[k] = vps[j];
-            }
-            Sl[rowi[j]][k] = v;
+        if (rowi[j] != 0xFF) {
+            Sl[rowi[j]][k] = vp[j];
             Pl[rowi[j]][k] = 1;
         }
+        if (k < K && lane == 0) zl[k] = vz[j];
+        if (k < K && lane == 1) sl[k] = vz[j];
     }
     __syncthreads();
     if (wave == 0) {
@@ -571,16 +560,313 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
     for (int j = 0; j < kTopJ; ++j) {
         const int k = wave + kTopWaves * j;
         if (k < K) {
-            double2 *Ck = A.C + cbj[j];
-            if (rowi[j] >= 0) Ck[1 + lane].y = Sl[rowi[j]][k];
+            double2 *Ck = A.C + inf[j].y;
+            if (rowi[j] != 0xFF) Ck[1 + lane].y = Sl[rowi[j]][k];
             if (lane == 0) {
                 const double t = tl[k];
                 Ck[0].y = t;
-                A.tvec[k] = t;
-                A.rdiag[k] = rl[k];
+                A.tvec[inf[j].x] = t;
+                A.rdiag[inf[j].x] = rl[k];
             }
         }
     }
+}
+
+// ---- the dense top block, two-block form: K up to 128 --------------------------------------------------------------------
+// The ~21 highest levels of the schedule hold 1-5 columns each (n = 1e6, m = 30, maxmin: profiles/r04_sgv_levels.txt), 6-7 us
+// apiece as launches.  The plan moves them into the block (gpv_api.hip), which then has up to 128 columns: A = the first 64
+// columns of the ordering, B = the others, and
+//     [ S_AA  S_AB ]   [ R_AA  R_AB ] [ R_AA  R_AB ]^T
+//     [  .    S_BB ] = [  0    R_BB ] [  0    R_BB ]      (on the pattern; off it R = 0, the level kernels' zero-fill rule)
+// Where the time of the one-block kernel goes (ablated builds, round 4): 11 of its 25 us are the serial chain pivot -> column
+// -> pivot, 13 us the 2016 rank-1 update FMAs with their LDS broadcasts, issued by ONE wavefront at ~10 cycles apiece.  Here a
+// 64-column block is factorised in panels of 16 columns: inside a panel the register chain as before (lane = row, register =
+// column, <= 15 update FMAs per step), and before a panel is entered everything the finished columns owe it is applied at
+// once as v_mfma_f64_16x16x4 tiles on operands that sit in LDS anyway (every finished column is stored there for the broadcasts).
+// Eight wavefronts:
+//   wave 0  factorises S_BB, panel by panel; after each panel a workgroup barrier;
+//   wave 1  one panel behind: the rectangle R_AB (rows of A, columns of B): R_ic = S_ic / R_cc, the panel's MFMA update from
+//           its own finished columns and wave 0's rows of R_BB, s_i += R_ic t_c;
+//   all     S_AA -= R_AB R_AB^T as MFMA tiles (upper triangle of 16 x 16 tiles);
+//   wave 0  factorises the updated S_AA.
+constexpr int kTop2 = 2 * kTop, kPan = 16, kLd = kTop + 1;        // panel width; row stride of a block in LDS (doubles)
+typedef double gpv_v4d __attribute__((ext_vector_type(4)));
+// NT 16 x 16 tiles at once: D_t[i][j] -= sum_{k in [kbeg, 64)} A_t[i][k] B_t[j][k], t = 0 .. NT-1; pointers to element (0, 0) of
+// tile 0 of each operand, rows kLd apart, tile t at + t SA / SB / SD doubles (0: the operand is shared).  64 - kbeg is a
+// multiple of 16.  The tiles are independent accumulation chains: a dependent MFMA waits for its predecessor.
+// v_mfma_f64_16x16x4_f64: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]; result register r of lane l is
+// D[(l >> 4) + 4 r][l & 15] (cdna_hip_programming.md, "f64 MFMA does NOT use these maps").
+template <int NT, int SA, int SB, int SD>
+__device__ __forceinline__ void top_mfma_tiles(const double *Ap, const double *Bp, double *Dp, const int kbeg, const int lane)
+{
+    const int li = lane & 15, lk = lane >> 4;
+    gpv_v4d acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] = Dp[t * SD + (lk + 4 * r) * kLd + li];
+    const double *ap = Ap + li * kLd + lk, *bp = Bp + li * kLd + lk;
+#pragma nounroll
+    for (int kk = kbeg; kk < kTop; kk += 8) {
+        double a0[NT], a1[NT], b0[NT], b1[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            a0[t] = -ap[t * SA + kk];
+            a1[t] = -ap[t * SA + kk + 4];
+            b0[t] = bp[t * SB + kk];
+            b1[t] = bp[t * SB + kk + 4];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[t], b0[t], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[t], b1[t], acc[t], 0, 0, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Dp[t * SD + (lk + 4 * r) * kLd + li] = acc[t][r];
+}
+constexpr int kRowTile = kPan * kLd;                              // 16 rows down
+// 0 in a vector register the compiler knows nothing about
+__device__ __forceinline__ int top_vzero()
+{
+    int z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+// one step of a panel of the triangular factorisation: column c = c0 + C.  S: the panel's 16 columns of this lane's row; pv: in
+// lane c the pivot's radicand (S_cc with everything subtracted).  The panels are a LOOP over c0, not unrolled code: the fully
+// unrolled 64-step chain of the one-block kernel is ~90 KB of instructions that run once, and its time follows its instruction
+// count whatever the instructions are (ablations, round 4): instruction fetch.  16 steps are ~8 KB and stay in the cache.
+template <int C>
+struct PanelStep {
+    static __device__ __forceinline__ void run(double (&S)[kPan], double *Sb, const double *bc, const int c0, const unsigned long long m,
+                                               const int lane, const double z2, double &sv, double &tv, double &rd, double &ri,
+                                               const double pv)
+    {
+        const int c = c0 + C;
+        double rn, rninv;
+        top_pivot(readlane_f64(pv, c), rn, rninv);
+        const double Rn = ((m >> c) & 1ull) ? ((lane == c) ? rn : top_div(S[C], rn, rninv)) : 0.0;
+        Sb[lane * kLd + c] = Rn;                                   // the finished column: broadcasts below, MFMA operand later
+        const double tc = top_div(readlane_f64(z2, c) - readlane_f64(sv, c), rn, rninv);
+        if (lane == c) { tv = tc; rd = rn; ri = rninv; }
+        sv = __builtin_fma(Rn, tc, sv);
+        if constexpr (C > 0) {
+            const double nR = -Rn;
+            // the next pivot from the lane's own registers (in lane c-1 the broadcast R_(c-1)c IS its Rn: same bits), so that
+            // the serial chain pivot -> column -> pivot does not pass through LDS
+            const double pn = __builtin_fma(nR, Rn, S[C - 1]);
+#pragma unroll
+            for (int k = 0; k < C; ++k) S[k] = __builtin_fma(nR, bc[k * kLd + C], S[k]);        // R_kc: lane k's value
+            PanelStep<C - 1>::run(S, Sb, bc, c0, m, lane, z2, sv, tv, rd, ri, pn);
+        }
+    }
+};
+// the whole block in LDS at Sb (64 x 64, rows kLd apart; on exit it holds R); m: this row's pattern bits; z2, sv: z2 and s of
+// the row; tl / rl / il: t, pivot and reciprocal pivot per column (out).  SYNC: a workgroup barrier after every panel
+template <bool SYNC>
+__device__ __forceinline__ void top_factor_block(double *Sb, const unsigned long long m, const int lane, const double z2, double &sv,
+                                                 double *tl, double *rl, double *il)
+{
+    double tv = 0.0, rd = 1.0, ri = 1.0;
+#pragma nounroll
+    for (int pn = kTop / kPan - 1; pn >= 0; --pn) {
+        const int c0 = kPan * pn;
+        // what the finished columns [c0 + 16, 64) owe this panel: row tiles at or above its diagonal only
+        if (pn == 2) top_mfma_tiles<3, kRowTile, 0, kRowTile>(Sb, Sb + c0 * kLd, Sb + c0, c0 + kPan, lane);
+        else if (pn == 1) top_mfma_tiles<2, kRowTile, 0, kRowTile>(Sb, Sb + c0 * kLd, Sb + c0, c0 + kPan, lane);
+        else if (pn == 0) top_mfma_tiles<1, kRowTile, 0, kRowTile>(Sb, Sb + c0 * kLd, Sb + c0, c0 + kPan, lane);
+        double S[kPan];
+#pragma unroll
+        for (int j = 0; j < kPan; ++j) S[j] = Sb[lane * kLd + c0 + j];
+        // (the broadcast addresses: ONE per-lane base register + immediate offsets; a uniform base makes the compiler build
+        //  every address in scalar registers and move it to a vector register, three instructions per read)
+        PanelStep<kPan - 1>::run(S, Sb, Sb + c0 * (kLd + 1) + top_vzero(), c0, m, lane, z2, sv, tv, rd, ri, S[kPan - 1]);
+        tl[lane] = tv;                                             // (final for the lanes of the finished panels)
+        rl[lane] = rd;
+        il[lane] = ri;
+        if constexpr (SYNC) top_wg_barrier();
+    }
+}
+// the rectangle (rows of A, columns of B): Sr its block, Sq the block of R_BB; rl / il / tl: wave 0's pivots and t
+template <int C>
+struct RectStep {
+    static __device__ __forceinline__ void run(double (&S)[kPan], double *Sr, const double *bc, const int c0, const unsigned long long m,
+                                               const int lane, double &sv, const double *rl, const double *il, const double *tl)
+    {
+        const int c = c0 + C;
+        const double Ric = ((m >> c) & 1ull) ? top_div(S[C], rl[c], il[c]) : 0.0;
+        Sr[lane * kLd + c] = Ric;
+        sv = __builtin_fma(Ric, tl[c], sv);
+        if constexpr (C > 0) {
+            const double nR = -Ric;
+#pragma unroll
+            for (int k = 0; k < C; ++k) S[k] = __builtin_fma(nR, bc[k * kLd + C], S[k]);
+            RectStep<C - 1>::run(S, Sr, bc, c0, m, lane, sv, rl, il, tl);
+        }
+    }
+};
+__device__ __forceinline__ void top_rect_block(double *Sr, const double *Sq, const unsigned long long m, const int lane, double &sv,
+                                               const double *rl, const double *il, const double *tl)
+{
+#pragma nounroll
+    for (int pn = kTop / kPan - 1; pn >= 0; --pn) {
+        const int c0 = kPan * pn;
+        top_wg_barrier();                                          // wave 0 has finished this panel
+        if (pn < kTop / kPan - 1) top_mfma_tiles<4, kRowTile, 0, kRowTile>(Sr, Sq + c0 * kLd, Sr + c0, c0 + kPan, lane);
+        double S[kPan];
+#pragma unroll
+        for (int j = 0; j < kPan; ++j) S[j] = Sr[lane * kLd + c0 + j];
+        RectStep<kPan - 1>::run(S, Sr, Sq + c0 * (kLd + 1) + top_vzero(), c0, m, lane, sv, rl, il, tl);
+    }
+}
+__device__ __forceinline__ unsigned long long top_mask_row(const unsigned char *Pb)
+{
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int c = 0; c < kTop; ++c) m |= (unsigned long long)Pb[c] << c;
+    return m;
+}
+// 8 waves: two of them carry the serial chains, all of them load, fill, update S_AA and store (a wavefront issues one
+// instruction per ~5 cycles whatever it is: the phases around the chains are instruction counts divided by the waves)
+constexpr int kTop2Waves = 8, kTop2J = kTop2 / kTop2Waves;      // (16 waves = 128 registers each: the chain spills)
+constexpr size_t kTop2Blk = (size_t)kTop * kLd;                   // doubles per 64 x 64 block (rows padded by one)
+constexpr size_t kTop2Smem = (3 * kTop2Blk + 5 * kTop2) * sizeof(double) + kTop2 * sizeof(int) + 3 * (size_t)kTop * kTop +
+                             (size_t)kTop2 * kTop;
+__global__ void __launch_bounds__(64 * kTop2Waves) gpv_posterior_top2_kernel(const PostArgs A, const double *tpart, const int K,
+                                                                            const int2 *topinfo, const uint8_t *toprows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char top2_smem[];
+    double *zl = reinterpret_cast<double *>(top2_smem), *sl = zl + kTop2, *tl = sl + kTop2, *rl = tl + kTop2, *il = rl + kTop2;
+    int *cbl = reinterpret_cast<int *>(il + kTop2);            // [column] its block's offset in C
+    unsigned char *P3 = reinterpret_cast<unsigned char *>(cbl + kTop2);
+    unsigned char *rowl = P3 + 3 * kTop * kTop;                // [column][entry]: the entry's row, 0xFF: none (kept for the stores)
+    // block 0: rows A x columns A, 1: rows A x columns B, 2: rows B x columns B; by (row, column), local indices
+    double *S3 = reinterpret_cast<double *>(rowl + (size_t)kTop2 * kTop);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto sidx = [](int r, int k) -> size_t {                   // (row, column) of the 128 x 128 block, r <= k
+        const int b = (k < kTop) ? 0 : ((r < kTop) ? 1 : 2);
+        return (size_t)b * kTop2Blk + (size_t)(r & (kTop - 1)) * kLd + (k & (kTop - 1));
+    };
+    auto pidx = [](int r, int k) -> size_t {
+        const int b = (k < kTop) ? 0 : ((r < kTop) ? 1 : 2);
+        return (size_t)b * kTop * kTop + (size_t)(r & (kTop - 1)) * kTop + (k & (kTop - 1));
+    };
+#ifdef GPV_TOP_TRACE
+    unsigned long long stamp[6];
+    stamp[0] = wall_clock64();
+#endif
+    // one trip: wave w loads the columns w, w + 4, ..: lane = entry of the column (its row in the block, its sum); the
+    // column's place in memory is only needed for the stores
+    int rowi[kTop2J];
+    double vp[kTop2J];
+#pragma unroll
+    for (int j = 0; j < kTop2J; ++j) {
+        const int k = wave + kTop2Waves * j;
+        const bool in = k < K;
+        rowi[j] = in ? (int)toprows[kTop * k + lane] : 0xFF;
+        vp[j] = in ? tpart[66 * (size_t)k + lane] : 0.0;
+    }
+    double c_z = 0.0, c_s = 0.0;
+    int2 inf = make_int2(0, 0);
+    if (tid < K) {                                              // (K <= 128 <= threads)
+        c_z = tpart[66 * (size_t)tid + 64];
+        c_s = tpart[66 * (size_t)tid + 65];
+        inf = topinfo[tid];
+    }
+    // (the blocks are NOT cleared: an entry off the pattern is never used, the steps select 0 for it by the pattern bit, and
+    //  what the tile updates do to it stays in it; the finished columns, the tiles' operands, are written for every row)
+    for (int i = tid; i < 3 * kTop * kTop / 8; i += 64 * kTop2Waves) reinterpret_cast<unsigned long long *>(P3)[i] = 0ull;
+#ifdef GPV_TOP_TRACE
+    const unsigned long long st_a = wall_clock64();
+#endif
+    if (tid < kTop2) { zl[tid] = c_z; sl[tid] = c_s; cbl[tid] = inf.y; }
+    __syncthreads();
+#ifdef GPV_TOP_TRACE
+    const unsigned long long st_b = wall_clock64();
+#endif
+    if (tid < kTop && kTop + tid >= K) {                        // columns past K: identity (R = 1, t = 0)
+        S3[sidx(kTop + tid, kTop + tid)] = 1.0;
+        P3[pidx(kTop + tid, kTop + tid)] = 1;
+    }
+#pragma unroll
+    for (int j = 0; j < kTop2J; ++j) {
+        const int k = wave + kTop2Waves * j;
+        rowl[k * kTop + lane] = (unsigned char)rowi[j];
+        if (rowi[j] != 0xFF) {
+            S3[sidx(rowi[j], k)] = vp[j];
+            P3[pidx(rowi[j], k)] = 1;
+        }
+    }
+    __syncthreads();
+#ifdef GPV_TOP_TRACE
+    stamp[1] = wall_clock64();
+#endif
+    double *SA = S3, *SR = S3 + kTop2Blk, *SB = S3 + 2 * kTop2Blk;
+    constexpr int NP = kTop / kPan;
+    if (wave == 0) {
+        const unsigned long long m = top_mask_row(P3 + 2 * kTop * kTop + lane * kTop);
+        double sv = sl[kTop + lane];
+        top_factor_block<true>(SB, m, lane, zl[kTop + lane], sv, tl + kTop, rl + kTop, il + kTop);                      // 4 barriers
+    } else if (wave == 1) {
+        const unsigned long long m = top_mask_row(P3 + kTop * kTop + lane * kTop);
+        double sv = sl[lane];
+        top_rect_block(SR, SB, m, lane, sv, rl + kTop, il + kTop, tl + kTop);                                           // 4 barriers
+        sl[lane] = sv;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) top_wg_barrier();
+    }
+    top_wg_barrier();                                           // R_AB is complete
+#ifdef GPV_TOP_TRACE
+    stamp[2] = wall_clock64();
+#endif
+    {
+        // S_AA -= R_AB R_AB^T, the 10 tiles (I, J >= I), dealt to the waves
+#pragma nounroll
+        for (int t = wave; t < 10; t += kTop2Waves) {
+            const int I = t < 4 ? 0 : (t < 7 ? 1 : (t < 9 ? 2 : 3));
+            const int J = t - (I == 0 ? 0 : (I == 1 ? 3 : (I == 2 ? 5 : 6)));
+            top_mfma_tiles<1, 0, 0, 0>(SR + I * kRowTile, SR + J * kRowTile, SA + I * kRowTile + kPan * J, 0, lane);
+        }
+    }
+    top_wg_barrier();
+#ifdef GPV_TOP_TRACE
+    stamp[3] = wall_clock64();
+#endif
+    if (wave == 0) {
+        const unsigned long long m = top_mask_row(P3 + lane * kTop);
+        double sv = sl[lane];
+        top_factor_block<false>(SA, m, lane, zl[lane], sv, tl, rl, il);
+    }
+    __syncthreads();
+#ifdef GPV_TOP_TRACE
+    stamp[4] = wall_clock64();
+#endif
+#pragma unroll
+    for (int j = 0; j < kTop2J; ++j) {
+        const int k = wave + kTop2Waves * j;
+        if (k < K) {
+            const int r = rowl[k * kTop + lane];
+            const int cb = cbl[k];
+            if (r != 0xFF) A.C[cb + 1 + lane].y = S3[sidx(r, k)];
+        }
+    }
+    if (tid < K) {
+        const double t = tl[tid];
+        A.C[inf.y].y = t;
+        A.tvec[inf.x] = t;
+        A.rdiag[inf.x] = rl[tid];
+    }
+#ifdef GPV_TOP_TRACE
+    if (tid == 0) {
+        stamp[5] = wall_clock64();
+        printf("[gpv top2] K %d  load %.2f (zeroed %.2f, loads in %.2f)  B and rectangle %.2f  A update %.2f  A %.2f  store %.2f us\n", K,
+               (double)(stamp[1] - stamp[0]) * 0.01, (double)(st_a - stamp[0]) * 0.01, (double)(st_b - stamp[0]) * 0.01, (double)(stamp[2] - stamp[1]) * 0.01, (double)(stamp[3] - stamp[2]) * 0.01,
+               (double)(stamp[4] - stamp[3]) * 0.01, (double)(stamp[5] - stamp[4]) * 0.01);
+    }
+#endif
 }
 
 // (GPV_POST_ZST=0 in the environment keeps the cross-lane butterflies: same-box A/B of the tile-row sums)
@@ -591,10 +877,11 @@ static bool zst_enabled(int ld)
 }
 
 // the top block: positions [first, first + K) of the column records hold the columns 0 .. K-1; tpart: [K][66] scratch
-hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, hipStream_t s)
+hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, const int2 *topinfo, const uint8_t *toprows,
+                                hipStream_t s)
 {
     if (K <= 0) return hipSuccess;
-    if (K > kTop) return hipErrorInvalidValue;
+    if (K > kTopMax) return hipErrorInvalidValue;
     const size_t smem = (size_t)16 * (a.ld + 2) * kTS * sizeof(double);
     const bool zst = zst_enabled(a.ld);
     if (smem > 64 * 1024) {                                   // > 64 KiB of dynamic LDS needs the opt-in, once per device
@@ -612,7 +899,23 @@ hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpa
     }
     if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, true>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
     else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, false>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
-    hipLaunchKernelGGL(gpv_posterior_top_kernel, dim3(1), dim3(64 * kTopWaves), 0, s, a, (const double *)tpart, K);
+    if (K <= kTop) {
+        hipLaunchKernelGGL(gpv_posterior_top_kernel, dim3(1), dim3(64 * kTopWaves), 0, s, a, (const double *)tpart, K, topinfo, toprows);
+        return hipGetLastError();
+    }
+    {
+        static std::atomic<unsigned long long> done2{0ull};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(done2.load(std::memory_order_relaxed) & bit)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_top2_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTop2Smem);
+            done2.fetch_or(bit, std::memory_order_relaxed);
+        }
+    }
+    hipLaunchKernelGGL(gpv_posterior_top2_kernel, dim3(1), dim3(64 * kTop2Waves), kTop2Smem, s, a, (const double *)tpart, K, topinfo,
+                       toprows);
     return hipGetLastError();
 }
 
@@ -773,14 +1076,31 @@ hipError_t launch_negate(const double *src, double *dst, int64_t n, hipStream_t 
 }
 
 // ---- deterministic pair reduction: out[0] = sum log x, out[1] = sum y^2 --------------------------------
+// sum log x_i = log(prod of the mantissas) + ln 2 * (sum of the exponents): one frexp and one multiplication per element and
+// ONE log per thread, instead of a ~100-instruction log() per element (the kernel was bound by them: 10.9 us for 16 MB).
+// A thread multiplies at most kSumPairRun mantissas (each in [0.5, 1)) before it takes the logarithm: no underflow.
+constexpr int kSumPairBlocks = 1024, kSumPairRun = 512;
 __global__ void __launch_bounds__(256) gpv_sum_pair_stage1(const double *x, const double *y, int64_t n, double *partials)
 {
     __shared__ double sx[256], sy[256];
-    double ax = 0.0, ay = 0.0;
+    double ax = 0.0, ay = 0.0, prod = 1.0;
+    int ex = 0, run = 0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        ax += log(x[i]);
-        ay = __builtin_fma(y[i], y[i], ay);
+        const double xi = x[i], yi = y[i];
+        if (xi > 0.0 && xi < 1.79e308) {                      // (anything else: through log(), which knows what to return)
+            prod *= __builtin_amdgcn_frexp_mant(xi);
+            ex += __builtin_amdgcn_frexp_exp(xi);
+            if (++run == kSumPairRun) {
+                ax += log(prod);
+                prod = 1.0;
+                run = 0;
+            }
+        } else {
+            ax += log(xi);
+        }
+        ay = __builtin_fma(yi, yi, ay);
     }
+    ax += log(prod) + 0.6931471805599453094 * (double)ex;
     sx[threadIdx.x] = ax;
     sy[threadIdx.x] = ay;
     __syncthreads();
@@ -798,10 +1118,11 @@ __global__ void __launch_bounds__(256) gpv_sum_pair_stage1(const double *x, cons
 }
 // second stage, fused with the patch of the likelihood sums: sums[2] = log det W = 2 sum log R_kk,
 // sums[3] = quadform.denom = sum t_k^2 (mirrored to sums_copy); 4 partials per lane, then a fixed tree
-__global__ void __launch_bounds__(64) gpv_sum_pair_stage2(const double *partials, int nb, double *sums, double *sums_copy)
+__global__ void __launch_bounds__(256) gpv_sum_pair_stage2(const double *partials, int nb, double *sums, double *sums_copy)
 {
+    __shared__ double px[4], py[4];
     double sx = 0.0, sy = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 64) {
+    for (int b = threadIdx.x; b < nb; b += 256) {
         sx += partials[2 * b];
         sy += partials[2 * b + 1];
     }
@@ -810,18 +1131,20 @@ __global__ void __launch_bounds__(64) gpv_sum_pair_stage2(const double *partials
         sx += __shfl_down(sx, off, 64);
         sy += __shfl_down(sy, off, 64);
     }
+    if ((threadIdx.x & 63) == 0) { px[threadIdx.x >> 6] = sx; py[threadIdx.x >> 6] = sy; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const double a = 2.0 * sx;
-        sums[2] = a; sums[3] = sy;
-        if (sums_copy != nullptr) { sums_copy[2] = a; sums_copy[3] = sy; }
+        const double a = 2.0 * ((px[0] + px[1]) + (px[2] + px[3])), q = (py[0] + py[1]) + (py[2] + py[3]);
+        sums[2] = a; sums[3] = q;
+        if (sums_copy != nullptr) { sums_copy[2] = a; sums_copy[3] = q; }
     }
 }
 hipError_t launch_sum_pair(const double *x, const double *y, int64_t n, double *partials, double *sums, double *sums_copy,
                            hipStream_t s)
 {
-    const int nb = 256;
+    const int nb = kSumPairBlocks;                             // (partials: 2 * kSumPairBlocks doubles)
     hipLaunchKernelGGL(gpv_sum_pair_stage1, dim3(nb), dim3(256), 0, s, x, y, n, partials);
-    hipLaunchKernelGGL(gpv_sum_pair_stage2, dim3(1), dim3(64), 0, s, partials, nb, sums, sums_copy);
+    hipLaunchKernelGGL(gpv_sum_pair_stage2, dim3(1), dim3(256), 0, s, partials, nb, sums, sums_copy);
     return hipGetLastError();
 }
 

@@ -9,9 +9,13 @@ namespace gpv {
 // most kMeanHeadMax columns wide; levptr2: device copy of the level offsets into order2
 constexpr int kMeanHeadMax = 32;
 hipError_t launch_mean_head(const PostArgs &a, const int32_t *order2, double *u, const int32_t *levptr2, int nlev, hipStream_t s);
-// Factor pass: the dense top block, columns 0 .. K-1 (K <= kTopMax) of the ordering, which the plan keeps out of the level
-// schedule (gpv_posterior.hip, gpv_posterior_top_kernel).  Their column records sit at positions [first, first + K) of
-// colrec, ascending, with colrec[..][1].y = the end of the row-list entries that are top columns themselves; tpart: [K][66].
-constexpr int kTopMax = 64;
-hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, hipStream_t s);
+// Factor pass: the dense top block (gpv_posterior.hip, gpv_posterior_top_kernel / gpv_posterior_top2_kernel): a set T of K <=
+// kTopMax columns the plan keeps out of the level schedule: the first kTopBlock columns of the ordering and, in the two-block
+// form, the columns of the schedule's highest levels (T is closed: the rows of its columns are in T, and no column outside T
+// waits for one inside).  Their column records sit at positions [first, first + K) of colrec, ascending; rowrec[q].w flags
+// the row-list pairs whose column is in T; tpart: [K][66]; topinfo[j] = {column, its block's offset in C}; toprows[j][e] = the
+// index INSIDE the block of entry e's row (0xFF: no such entry).
+constexpr int kTopBlock = 64, kTopMax = 2 * kTopBlock;
+hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, const int2 *topinfo, const uint8_t *toprows,
+                                hipStream_t s);
 }  // namespace gpv

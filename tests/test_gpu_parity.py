@@ -756,7 +756,7 @@ def test_sgv_posterior_pass_wide_levels():
     va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
     ll = G.vecchia_likelihood(z, va, cp, tau)
     plan = va[("_plan", 0)]
-    assert plan.has_posterior and plan.posterior_levels() > 40
+    assert plan.has_posterior and plan.posterior_levels() > 20         # (the highest ~20 levels are in the dense top block)
     s1 = plan.sums().copy()
     ll_host = G.vecchia_likelihood_U(z, G.createU(va, cp, tau))
     assert abs(ll - ll_host) <= 1e-9 * abs(ll_host)
@@ -770,7 +770,7 @@ import numpy as np
 import torch  # noqa: F401  (one HIP runtime per process: conftest.py)
 import gpvecchia_amd as G
 out = {}
-for n, m in [(40, 10), (63, 20), (64, 20), (65, 20), (700, 30), (5000, 25)]:
+for n, m in [(40, 10), (63, 20), (64, 20), (65, 20), (100, 30), (128, 20), (129, 20), (700, 30), (5000, 25)]:
     rng = np.random.default_rng(n)
     locs = rng.random((n, 2)); z = rng.standard_normal(n)
     tau = 0.1 + 0.2 * rng.random(n)
@@ -784,27 +784,31 @@ print("RESULT" + json.dumps(out))
 
 
 def test_dense_top_block_of_posterior_pass_matches_level_schedule():
-    # the first min(n, 64) columns of the ordering are factorised by gpv_posterior_top_kernel instead of ~35 single-column
-    # levels; GPV_POST_TOP=0 schedules every column.  Same factor (different summation order): the log-likelihood, the
-    # log-determinant / quadratic form of W and the posterior mean agree to rounding, for n below, at and above the block size
+    # the first min(n, 128) columns of the ordering are factorised by gpv_posterior_top_kernel (one 64-column block) or
+    # gpv_posterior_top2_kernel (two) instead of ~55 levels of 1-5 columns; GPV_POST_TOP=0 schedules every column, =64 keeps the
+    # one-block form.  Same factor (different summation order): the log-likelihood, the log-determinant / quadratic form of W
+    # and the posterior mean agree to rounding, for n below, at and above the block sizes
     _need_gpu()
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for top in ("0", "1"):
+    for top in ("0", "64", "128"):
         env = dict(os.environ, GPV_POST_TOP=top, PYTHONPATH=root)
         r = subprocess.run([sys.executable, "-c", _TOP_SNIPPET], capture_output=True, text=True, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         res[top] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
-    for key, a in res["0"].items():
-        b = res["1"][key]
-        assert b["levels"] < a["levels"] or int(key) <= 64
-        assert abs(a["ll"] - b["ll"]) <= 1e-11 * abs(a["ll"]), key
-        np.testing.assert_allclose(b["sums"][2:4], a["sums"][2:4], rtol=1e-11, err_msg=key)
-        np.testing.assert_allclose(b["mu"], a["mu"], rtol=0, atol=1e-10 * np.abs(a["mu"]).max(), err_msg=key)
-    assert res["1"]["40"]["levels"] == 0 and res["1"]["64"]["levels"] == 0 and res["1"]["65"]["levels"] == 1
+    for top in ("64", "128"):
+        for key, a in res["0"].items():
+            b = res[top][key]
+            assert b["levels"] < a["levels"] or int(key) <= int(top), (top, key)
+            assert abs(a["ll"] - b["ll"]) <= 1e-11 * abs(a["ll"]), (top, key)
+            np.testing.assert_allclose(b["sums"][2:4], a["sums"][2:4], rtol=1e-11, err_msg=top + " " + key)
+            np.testing.assert_allclose(b["mu"], a["mu"], rtol=0, atol=1e-10 * np.abs(a["mu"]).max(), err_msg=top + " " + key)
+    assert res["64"]["40"]["levels"] == 0 and res["64"]["64"]["levels"] == 0 and res["64"]["65"]["levels"] == 1
+    assert res["128"]["100"]["levels"] == 0 and res["128"]["128"]["levels"] == 0 and res["128"]["129"]["levels"] == 1
+    assert res["128"]["5000"]["levels"] < res["64"]["5000"]["levels"]
 
 
 def test_plans_release_their_device_memory():
