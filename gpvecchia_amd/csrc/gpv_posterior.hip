@@ -432,10 +432,12 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
 // ---- the dense top block ------------------------------------------------------------------------------------------
 // The first points of the ordering condition on (nearly) all of their predecessors and are conditioned on by thousands of
 // later points: as columns of the schedule they form a chain of ~35 single-column levels (n = 1e6, m = 30, maxmin), 5-8 us
-// each as launches of their own.  The plan therefore takes the columns k < K = min(n, 64) out of the schedule.  Their rows
-// lie inside the block (rows precede the column), so after every other column is final
-//   (1) gpv_posterior_level_kernel<16, 1> reduces, for all K columns at once, everything that does not involve the R and t
-//       of another top column (tpart: per column 64 row sums, B a, and the R t sum over the columns outside the block), and
+// each as launches of their own.  The plan therefore takes a set T of columns out of the schedule (gpv_posterior_ext.h): here
+// the K = min(n, 64) first ones, in the two-block kernel below up to 128.  Their rows lie inside T, so after every other
+// column is final
+//   (1) gpv_posterior_level_kernel<16, 1> computes, for all K columns at once, everything that does not involve the R and t
+//       of another column of T (tpart: per column its 64 entries S_ik = B B^T terms + B_ik d_k (+ 1/tau on the diagonal), z2
+//       with the data term, and the R t sum over the columns outside T), and
 //   (2) this kernel finishes the block as a dense UL factorisation held in the registers of ONE wavefront: lane i owns row
 //       i, register c column c; for c = 63 .. 0: R_cc = sqrt(S_cc), R_ic = S_ic / R_cc on the pattern (an entry off the
 //       pattern stays 0: the zero-fill rule of the level kernels), t_c = (z2_c - s_c) / R_cc, then S_ik -= R_ic R_kc for
