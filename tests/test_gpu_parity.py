@@ -770,9 +770,11 @@ import numpy as np
 import torch  # noqa: F401  (one HIP runtime per process: conftest.py)
 import gpvecchia_amd as G
 out = {}
-for n, m in [(40, 10), (63, 20), (64, 20), (65, 20), (100, 30), (128, 20), (129, 20), (700, 30), (5000, 25)]:
+# (n, m, dimension): 62 neighbours = 63-entry columns, the level kernel's form without the tile-row sums of z2 and s
+for n, m, d in [(40, 10, 2), (63, 20, 2), (64, 20, 2), (65, 20, 2), (100, 30, 2), (128, 20, 2), (129, 20, 2), (700, 30, 2), (5000, 25, 2),
+                (400, 62, 3)]:
     rng = np.random.default_rng(n)
-    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    locs = rng.random((n, d)); z = rng.standard_normal(n)
     tau = 0.1 + 0.2 * rng.random(n)
     va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV")
     ll = G.vecchia_likelihood(z, va, [1.3, 0.2, 1.5], tau)
