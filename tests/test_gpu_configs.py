@@ -10,6 +10,8 @@ on sampled rows plus size-independent properties at the full sizes.
 
 Tolerances as in test_gpu_parity.py: index arrays bit-exact, U entries 1e-8 normwise per row, log-likelihood 1e-8
 relative (1e-7 for the Vecchia-Laplace quantities, which sit behind a Newton iteration stopped at 1e-6)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -489,3 +491,50 @@ def test_grid_nn_search_is_bit_exact(case):
     a, b = n // 3, n // 3 + 5000
     sh = S.find_ordered_nn_gpu(locs, m, rows=(a, b))
     assert np.array_equal(sh[a:b], NN[a:b]) and not sh[:a].any() and not sh[b:].any()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# bench.py --mode S at full size: the posterior pass with the dense top block against the same pass with every column in
+# the level schedule (different summation order, same factor)
+# ----------------------------------------------------------------------------------------------------------------
+_TOP_FULL_SNIPPET = r"""
+import json
+import numpy as np
+import torch  # noqa: F401  (one HIP runtime per process: conftest.py)
+import gpvecchia_amd as G
+n, m = 1_000_000, 30
+rng = np.random.default_rng(0)
+locs = rng.random((n, 2)); z = np.random.default_rng(1).standard_normal(n)
+tau = 0.05 + 0.1 * rng.random(n)
+va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+ll = G.vecchia_likelihood(z, va, [1.0, 0.02, 1.5], tau)
+plan = va[("_plan", 0)]
+ll2 = G.vecchia_likelihood(z, va, [1.0, 0.02, 1.5], tau)
+mu = G.vecchia_prediction(z, va, [1.0, 0.02, 1.5], tau)["mu_obs"]
+idx = np.concatenate([np.arange(200), rng.integers(0, n, 2000)])
+print("RESULT" + json.dumps(dict(ll=ll, same=bool(ll == ll2), sums=plan.sums().tolist(), levels=plan.posterior_levels(),
+                                 mu=mu[idx].tolist(), mu_abs_max=float(np.abs(mu).max()))))
+"""
+
+
+def test_full_size_dense_top_block_n1e6_m30():
+    """n = 1e6, m = 30, maxmin + SGV (the reference's defaults; bench.py --mode S): with the dense top block the schedule is
+    ~21 levels shorter; log-likelihood, log det W, the quadratic form and the posterior mean agree with the all-levels pass to
+    rounding, and the evaluation is bitwise reproducible."""
+    _need_gpu()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for top in ("0", "128"):
+        env = dict(os.environ, GPV_POST_TOP=top, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", _TOP_FULL_SNIPPET], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[top] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+    a, b = res["0"], res["128"]
+    assert a["same"] and b["same"]
+    assert 15 <= a["levels"] - b["levels"] <= 70 and b["levels"] >= 60
+    assert abs(a["ll"] - b["ll"]) <= 1e-11 * abs(a["ll"])
+    np.testing.assert_allclose(b["sums"][2:4], a["sums"][2:4], rtol=1e-11)
+    np.testing.assert_allclose(b["mu"], a["mu"], rtol=0, atol=1e-10 * a["mu_abs_max"])
