@@ -973,6 +973,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
                                  : launch_posterior_compact(pl->d_L, pl->P, pl->d_avec, pl->d_colptr, pl->d_ccol, pl->d_cslot,
                                                             pl->d_cdel, pl->Nlocs, pl->post_nnz, pl->d_C, mean_b, st);
             if (mean_b) {
+                if (e == hipSuccess && pl->top_K > 0)
+                    e = launch_mean_top(pa, pl->d_u, pl->top_K, pl->d_topinfo, pl->d_toprows, st);
                 if (e == hipSuccess)
                     e = launch_mean_head(pa, pl->d_order2, pl->d_u, pl->d_levptr2, pl->mean_head_levels, st);
                 for (size_t lv = (size_t)pl->mean_head_levels; e == hipSuccess && lv + 1 < pl->levptr2.size(); ++lv)
@@ -989,6 +991,8 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             if (e == hipSuccess)
                 e = launch_sum_pair(pl->d_rdiag, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, mirror, st);
             if (want_mean) {
+                if (e == hipSuccess && pl->top_K > 0)
+                    e = launch_mean_top(pa, pl->d_u, pl->top_K, pl->d_topinfo, pl->d_toprows, st);
                 if (e == hipSuccess)
                     e = launch_mean_head(pa, pl->d_order2, pl->d_u, pl->d_levptr2, pl->mean_head_levels, st);
                 for (size_t lv = (size_t)pl->mean_head_levels; e == hipSuccess && lv + 1 < pl->levptr2.size(); ++lv)
@@ -1444,9 +1448,11 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         }
     }
     // second schedule for the posterior mean (R^T u = t): column k waits for the rows i < k it contains
+    // (the columns of the top block are solved first, by one dense substitution: launch_mean_top; they wait for nothing outside)
     std::vector<int32_t> lev2((size_t)n, 0);
     int32_t maxlev2 = 0;
     for (int64_t k = 0; k < n; ++k) {
+        if (in_top[(size_t)k]) { lev2[(size_t)k] = -1; continue; }
         int32_t l = 0;
         for (int32_t e = colptr[(size_t)k]; e < colptr[(size_t)k + 1]; ++e) {
             const int32_t i = crow[(size_t)e];
@@ -1456,10 +1462,12 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         if (l > maxlev2) maxlev2 = l;
     }
     pl->levptr2.assign((size_t)maxlev2 + 2, 0);
-    for (int64_t k = 0; k < n; ++k) pl->levptr2[(size_t)lev2[(size_t)k] + 1]++;
+    for (int64_t k = 0; k < n; ++k)
+        if (!in_top[(size_t)k]) pl->levptr2[(size_t)lev2[(size_t)k] + 1]++;
     for (int32_t l = 0; l <= maxlev2; ++l) pl->levptr2[(size_t)l + 1] += pl->levptr2[(size_t)l];
-    std::vector<int32_t> pos2(pl->levptr2.begin(), pl->levptr2.end() - 1), order2((size_t)n);
-    for (int64_t k = 0; k < n; ++k) order2[(size_t)pos2[(size_t)lev2[(size_t)k]]++] = (int32_t)k;
+    std::vector<int32_t> pos2(pl->levptr2.begin(), pl->levptr2.end() - 1), order2((size_t)(n - K));
+    for (int64_t k = 0; k < n; ++k)
+        if (!in_top[(size_t)k]) order2[(size_t)pos2[(size_t)lev2[(size_t)k]]++] = (int32_t)k;
 
     GPV_HIP(hipSetDevice(pl->device));
     {
@@ -1516,9 +1524,9 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     pl->post_nnz = (int64_t)nnz;
     if ((rc = up((void **)&pl->d_order2, order2.data(), order2.size() * 4)) != GPV_OK) return rc;
     {
-        std::vector<int4> meanrec((size_t)n);
-        for (int64_t i = 0; i < n; ++i) {
-            const int32_t k = order2[(size_t)i];
+        std::vector<int4> meanrec(order2.size());
+        for (size_t i = 0; i < order2.size(); ++i) {
+            const int32_t k = order2[i];
             meanrec[(size_t)i] = make_int4(k, cboff[(size_t)k], colptr[(size_t)k + 1] - colptr[(size_t)k], colptr[(size_t)k]);
         }
         if ((rc = up((void **)&pl->d_meanrec, meanrec.data(), meanrec.size() * sizeof(int4))) != GPV_OK) return rc;

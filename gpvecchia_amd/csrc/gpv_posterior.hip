@@ -1074,6 +1074,92 @@ hipError_t launch_mean_head(const PostArgs &a, const int32_t *order2, double *u,
     hipLaunchKernelGGL(gpv_mean_head_kernel, dim3(1), dim3(1024), 0, s, a, order2, u, levptr2, nlev);
     return hipGetLastError();
 }
+// The columns of the dense top block (gpv_posterior_ext.h) come first in the mean sweep too: the rows of a column of T are in
+// T, so R_TT^T u_T = t_T is a dense forward substitution of its own (u_j = (t_j - sum_{i<j} R_ij u_i) / R_jj), and the first
+// points of the ordering, a chain of ~35 one-column levels, are in T.  One wavefront, lane l owns the columns l and l + 64
+// of the block: as soon as u_j is known every lane adds R_jc u_j to the sum of its columns c (row j of R from LDS).
+constexpr size_t kMeanTopSmem = ((size_t)kTop2 * (kTop2 + 1) + 2 * kTop2) * sizeof(double);
+__global__ void __launch_bounds__(1024) gpv_mean_top_kernel(const PostArgs A, double *u, const int K, const int2 *topinfo,
+                                                          const uint8_t *toprows)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char mtop_smem[];
+    double *Rl = reinterpret_cast<double *>(mtop_smem);        // [row][column], rows kTop2 + 1 apart; 0 off the pattern
+    double *tl = Rl + (size_t)kTop2 * (kTop2 + 1), *ul = tl + kTop2;
+    constexpr int LD = kTop2 + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // column k of the block: entry e (lane) sits in row toprows[k][e]
+    int rowi[kTop2 / 16];
+    double val[kTop2 / 16];
+#pragma unroll
+    for (int j = 0; j < kTop2 / 16; ++j) {
+        const int k = wave + 16 * j;
+        rowi[j] = 0xFF;
+        val[j] = 0.0;
+        if (k < K) {
+            rowi[j] = (int)toprows[kTop * k + lane];
+            const int cb = topinfo[k].y;
+            if (rowi[j] != 0xFF) val[j] = A.C[(int64_t)cb + 1 + lane].y;
+        }
+    }
+    int2 inf = make_int2(0, 0);
+    double tk = 0.0;
+    if (tid < K) {
+        inf = topinfo[tid];
+        tk = A.tvec[inf.x];
+    }
+    for (int i = tid; i < kTop2 * LD; i += 1024) Rl[i] = 0.0;
+    if (tid < kTop2) tl[tid] = tk;
+    __syncthreads();
+    if (tid < kTop2 && tid >= K) Rl[tid * LD + tid] = 1.0;     // columns past K: u = 0
+#pragma unroll
+    for (int j = 0; j < kTop2 / 16; ++j) {
+        const int k = wave + 16 * j;
+        if (rowi[j] != 0xFF) Rl[rowi[j] * LD + k] = val[j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const double d0 = Rl[lane * LD + lane], d1 = Rl[(kTop + lane) * LD + kTop + lane];
+        const double ri0 = 1.0 / d0, ri1 = 1.0 / d1;
+        const double t0 = tl[lane], t1 = tl[kTop + lane];
+        double s0 = 0.0, s1 = 0.0, u0 = 0.0, u1 = 0.0;
+        const double *rp = Rl + lane;
+#pragma nounroll
+        for (int j = 0; j < kTop; ++j) {                       // columns of the first half
+            const double uj = readlane_f64(top_div(t0 - s0, d0, ri0), j);
+            if (lane == j) u0 = uj;
+            s0 = __builtin_fma(rp[j * LD], uj, s0);
+            s1 = __builtin_fma(rp[j * LD + kTop], uj, s1);
+        }
+        if (K > kTop) {
+#pragma nounroll
+            for (int j = 0; j < kTop; ++j) {                   // and of the second (their rows in the first half are done)
+                const double uj = readlane_f64(top_div(t1 - s1, d1, ri1), j);
+                if (lane == j) u1 = uj;
+                s1 = __builtin_fma(rp[(kTop + j) * LD + kTop], uj, s1);
+            }
+        }
+        ul[lane] = u0;
+        ul[kTop + lane] = u1;
+    }
+    __syncthreads();
+    if (tid < K) u[inf.x] = ul[tid];
+}
+hipError_t launch_mean_top(const PostArgs &a, double *u, int K, const int2 *topinfo, const uint8_t *toprows, hipStream_t s)
+{
+    if (K <= 0) return hipSuccess;
+    if (K > kTopMax) return hipErrorInvalidValue;
+    static std::atomic<unsigned long long> done{0ull};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_mean_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)kMeanTopSmem);
+        done.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(gpv_mean_top_kernel, dim3(1), dim3(1024), kMeanTopSmem, s, a, u, K, topinfo, toprows);
+    return hipGetLastError();
+}
 __global__ void gpv_negate_kernel(const double *src, double *dst, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)

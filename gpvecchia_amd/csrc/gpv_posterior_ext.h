@@ -18,4 +18,6 @@ hipError_t launch_mean_head(const PostArgs &a, const int32_t *order2, double *u,
 constexpr int kTopBlock = 64, kTopMax = 2 * kTopBlock;
 hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, const int2 *topinfo, const uint8_t *toprows,
                                 hipStream_t s);
+// Mean sweep, the columns of T: the plan's ascending schedule (order2 / levptr2 / meanrec) holds the OTHER columns only
+hipError_t launch_mean_top(const PostArgs &a, double *u, int K, const int2 *topinfo, const uint8_t *toprows, hipStream_t s);
 }  // namespace gpv
