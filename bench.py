@@ -725,6 +725,15 @@ def main():
                                      "sets_kernel_ms": km, "loglik": ll, "levels": nlev, "setup_s": round(ts, 2),
                                      "what": "the reference's defaults: ordering='maxmin', cond.yz='SGV'; set kernel + "
                                              "posterior pass (U2V) on one GPU; does not shard"}
+                    # the same evaluation with the posterior mean (R/vecchia_prediction.R:118-126: one more level-scheduled
+                    # sweep R^T u = t; what every Newton step of the Vecchia-Laplace loop runs)
+                    try:
+                        el, km, ll = measure(ps, G.GPV_WANT_DENOM | G.GPV_WANT_MEAN, True, args.steps, 2)
+                        sec["mode_S_mean"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
+                                              "sets_kernel_ms": km,
+                                              "what": "mode_S plus the posterior mean of the latent field at the observed locations"}
+                    except Exception as e:
+                        sec["mode_S_mean"] = {"error": repr(e)}
                     del ps
                     # mode L on the reference's DEFAULT ordering ("ordering='none' ... unless the maxmin builder
                     # exists"): maxmin with the cut-9 quirk (R/vecchia_specify.R:103-106), cond.yz='z', same locations / m / covparms
