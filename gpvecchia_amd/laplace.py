@@ -33,11 +33,11 @@ def _families(model, likparms):
     if model == "logistic":                                               # :213-223
         return dict(hess=lambda y, z: np.exp(y) / (1 + np.exp(y)) ** 2, score=lambda y, z: z - np.exp(y) / (1 + np.exp(y)),
                     llh=lambda y, z: np.sum(z * y - np.log(1 + np.exp(y))), link=lambda y: np.exp(y) / (1 + np.exp(y)),
-                    bad=lambda z: not np.all(np.isin(z, (0, 1))))
+                    bad=lambda z: not np.all((z == 0) | (z == 1)))
     if model == "poisson":                                                # :225-237
         return dict(hess=lambda y, z: np.exp(y), score=lambda y, z: z - np.exp(y),
                     llh=lambda y, z: np.sum(z * y - np.exp(y) - gammaln(z + 1)), link=lambda y: np.exp(y),
-                    bad=lambda z: bool(np.any(z < 0) or np.any(z % 1 > 0)))
+                    bad=lambda z: bool(np.any(z < 0) or np.any(z != np.floor(z))))   # R: any(z %% 1 > 0); (numpy fmod costs 5 ms at n = 5e5)
     if model == "gamma":                                                  # :266-276
         return dict(hess=lambda y, z: alpha * z * np.exp(-y), score=lambda y, z: alpha * (z * np.exp(-y) - 1),
                     llh=lambda y, z: np.sum(-alpha * z * np.exp(-y) + (alpha - 1) * np.log(z) - alpha * y

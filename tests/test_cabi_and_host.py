@@ -317,3 +317,26 @@ def test_r_layout_cache_sees_in_place_edits_and_holds_no_reference():
     del nn, a1, a2, a3, a4
     gc.collect()
     assert w() is None                                                  # only weak references inside the cache
+
+
+def test_vecchia_laplace_data_support_checks():
+    # R/vecchia_laplace_NR.R:48-54: the data must lie in the support of the likelihood (poisson: any(z < 0) | any(z %% 1 > 0);
+    # logistic: values in {0, 1}; gamma: z > 0; beta: 0 <= z <= 1); host-side checks, written without numpy's fmod / isin
+    from gpvecchia_amd.laplace import _families
+    lp = dict(alpha=2, sigma=0.3, beta=0.5)
+    cases = {
+        "poisson": [([0.0, 3.0, 7.0], False), ([1.0, 2.5], True), ([-1.0, 2.0], True), ([-0.5], True), ([np.inf], False)],
+        "logistic": [([0.0, 1.0, 1.0], False), ([0.0, 2.0], True), ([0.5], True)],
+        "gamma": [([0.1, 3.0], False), ([0.0, 1.0], True)],
+        "gamma_alt": [([0.1, 3.0], False), ([-1.0], True)],
+        "beta": [([0.0, 0.5, 1.0], False), ([1.5], True), ([-0.1], True)],
+        "gaussian": [([-3.0, 0.5], False)],
+    }
+    for model, rows in cases.items():
+        bad = _families(model, lp)["bad"]
+        for z, want in rows:
+            assert bool(bad(np.asarray(z))) is want, (model, z)
+    big = np.random.default_rng(0).poisson(1.5, 200_000).astype(float)
+    assert not _families("poisson", lp)["bad"](big)
+    big[123_456] += 0.25
+    assert _families("poisson", lp)["bad"](big)
