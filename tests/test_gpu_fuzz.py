@@ -107,3 +107,30 @@ def test_repeated_launches_are_bit_identical(m, d, n):
         assert np.array_equal(s, s0), (it, s - s0)
         if it % 8 == 7:
             assert np.array_equal(plan.Lentries(), L0), it
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_posterior_pass_random_plans_against_host_route(seed):
+    """The posterior pass (factor with its dense top block, denominator, posterior mean) on random plans whose sizes straddle
+    the block's limits of 64 and 128 columns, against the host route (createU + sparse LU, what the reference's Matrix calls
+    do): R/vecchia_prediction.R:62-83,118-126, R/vecchia_likelihood.R:85-90.  tools/fuzz_posterior.py is the same over 1000
+    seeds (profiles/r04_posterior_fuzz.txt)."""
+    G = _need_gpu()
+    from gpvecchia_amd import api as A
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.integers(1, 4))
+    n = int([rng.integers(5, 64), rng.integers(64, 130), rng.integers(130, 400), rng.integers(400, 3000)][seed % 4])
+    m = int(min(n - 1, rng.integers(2, 45)))
+    locs = rng.random((n, d))
+    z = rng.standard_normal(n)
+    nu = 0.5 if d == 1 else float(rng.choice([0.5, 1.5, 2.5]))
+    cp = [float(0.5 + rng.random()), float(0.05 + 0.3 * rng.random()), nu]
+    tau = 0.05 + 0.3 * rng.random(n) if rng.random() < 0.7 else float(0.05 + 0.3 * rng.random())
+    va = G.vecchia_specify(locs, m, ordering=str(rng.choice(["maxmin", "none"])), cond_yz=str(rng.choice(["SGV", "SGV", "y"])))
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    pred = G.vecchia_prediction(z, va, cp, tau)
+    U_obj = A.createU(va, cp, tau)
+    ll_h = A.vecchia_likelihood_U(z, U_obj)
+    mo_h, _ = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)
+    assert abs(ll - ll_h) <= 1e-9 * max(abs(ll_h), 1.0)
+    np.testing.assert_allclose(pred["mu_obs"], mo_h, rtol=0, atol=1e-8 * max(np.abs(mo_h).max(), 1e-300))
