@@ -6,7 +6,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
          "GRBM_GUI_ACTIVE FETCH_SIZE" "TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE"; do
   i=$((i+1))
-  GPV_NO_GRAPH=1 timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 bench.py --mode S --steps 2 --warmup 1 > $OUT/log$i.txt 2>&1
+  GPV_NO_GRAPH=1 timeout 300 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 bench.py --mode S --steps 2 --warmup 1 --no-cpu-baseline --clock-warmup-s 0 > $OUT/log$i.txt 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections, json
