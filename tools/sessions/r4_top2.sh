@@ -3,6 +3,8 @@
 # same-box A/B, and where the new kernel's time goes (traced build)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4top2; mkdir -p $O
+# the traced build (in-kernel stamps): python gpvecchia_amd/build.py --tag toptrace --flags=-DGPV_TOP_TRACE --plist 31
+[ -f gpvecchia_amd/libgpvecchia_hiptoptrace.so ] || python gpvecchia_amd/build.py --tag toptrace --flags=-DGPV_TOP_TRACE --plist 31 > /dev/null 2>&1
 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_prediction.py -q -x -m gpu 2>&1 | tail -5
 for t in 64 128 64 128; do
   GPV_POST_TOP=$t python bench.py --mode S --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
