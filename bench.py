@@ -149,6 +149,35 @@ def parity_in_run(gpu_L, gpu_loglik, gpu_nfail, kept, revNN, z, tau, n):
     return res
 
 
+def mode_S_oracle(va, z, covparms, tau, gpu_loglik, gpu_sums, gpu_mu_ord):
+    """Parity evidence for secondary.mode_S (outside every timed region): the oracle's SPARSE restatement of the R chain
+    createU -> U2V -> vecchia_likelihood_U / vecchia_mean (oracle/r_side.py: its own U entries, Matrix::tcrossprod by
+    scipy.sparse, its own natural-order sparse Cholesky) on the plan mode S was timed on, against what the GPU returned."""
+    from oracle import r_side as R
+    t0 = time.time()
+    prep = dict(va["U_prep"])
+    nn = prep["revNNarray"]
+    prep["revNNarray"] = np.where(nn == 0, np.nan, nn.astype(np.float64))
+    prep["revCond"] = np.where(prep["revCond"] < 0, np.nan, prep["revCond"].astype(np.float64))
+    ova = {k: v for k, v in va.items() if not isinstance(k, tuple)}
+    ova["U_prep"] = prep
+    Us = R.createU_sparse(ova, covparms, tau)
+    V = R.U2V_sparse(Us)
+    ll_o, t = R.vecchia_likelihood_U_sparse(z, Us, V=V, terms=True)
+    res = {"loglik_oracle": float(ll_o), "rel_err": float(abs(gpu_loglik - ll_o) / abs(ll_o)),
+           "logdet_denom_rel_err": float(abs(gpu_sums[2] + t["logdet_denom"]) / abs(t["logdet_denom"])),
+           "quadform_denom_rel_err": float(abs(gpu_sums[3] - t["quadform_denom"]) / abs(t["quadform_denom"])),
+           "nnz_V": int(V.nnz)}
+    if gpu_mu_ord is not None:
+        mu_o = R.vecchia_mean_sparse(z, Us, V, ordered=True)
+        res["mean_max_abs_err"] = float(np.abs(gpu_mu_ord - mu_o).max())
+        res["mean_abs_max"] = float(np.abs(mu_o).max())
+    res["oracle_s"] = round(time.time() - t0, 1)
+    res["what"] = ("HIP set kernel + posterior pass vs oracle.r_side.{createU_sparse,U2V_sparse,vecchia_likelihood_U_sparse,"
+                   "vecchia_mean_sparse} (R/vecchia_prediction.R:62-142, R/vecchia_likelihood.R:63-99) on the same plan")
+    return res
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -195,12 +224,41 @@ def self_launch(args):
         print(f"[bench] --gpus {args.gpus} but only {ndev} GPU(s) visible: refusing to report a {args.gpus}-GPU number",
               file=sys.stderr)
         return 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
-    return subprocess.run(cmd, env=env).returncode
+    # one fresh child per rank with the launcher contract's environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), started
+    # here rather than through torch.distributed.run so that a rank's exit code (3 = self-check failed, 4 = the collective
+    # guard expired) reaches the caller unchanged; when a rank fails, the others are ended by their exact PIDs
+    port = str(_free_port())
+    base = dict(os.environ)
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    base.update(WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r), GROUP_RANK="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for pr in list(alive):
+            code = pr.poll()
+            if code is None:
+                continue
+            alive.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                for other in alive:                       # a failed rank ends the job: the rest would wait in a collective
+                    other.terminate()
+                t_end = time.time() + 10.0
+                for other in alive:
+                    try:
+                        other.wait(timeout=max(0.1, t_end - time.time()))
+                    except subprocess.TimeoutExpired:
+                        other.kill()
+                        other.wait()
+                alive = []
+                break
+    return rc
 
 
 def other_config(name, device, measure_with, steps=10, b2b=None):
@@ -410,7 +468,8 @@ def main():
     # GPV_TORCH_ALLREDUCE=1: the round-2 route (dist.all_reduce on the plan's device buffer), kept for A/B
     comm, route = None, ("none (1 rank, no launcher)" if not use_dist else f"torch.distributed all_reduce ({backend})")
     guard = None
-    if use_dist and backend == "nccl" and args.mode != "S":
+
+    def arm_guard():
         # Wall-clock guard around the first contact with N ranks: creating the communicator and the first all-reduced
         # evaluation must finish within --comm-guard-s, else this rank says why and exits non-zero (the launcher then ends
         # the others): a hung collective must not look like a slow bench.  Disarmed after the first complete step.
@@ -421,9 +480,13 @@ def main():
                   f"communicator (route so far: {route}); exiting 4.  GPV_TORCH_ALLREDUCE=1 selects the torch.distributed route.",
                   file=sys.stderr, flush=True)
             os._exit(4)
-        guard = threading.Timer(args.comm_guard_s, _expired)
-        guard.daemon = True
-        guard.start()
+        g = threading.Timer(args.comm_guard_s, _expired)
+        g.daemon = True
+        g.start()
+        return g
+
+    if use_dist and backend == "nccl" and args.mode != "S":
+        guard = arm_guard()
         from gpvecchia_amd.distributed import negotiate_comm
         comm, why = negotiate_comm(local_rank, None, timeout_s=min(120.0, args.comm_guard_s / 2),
                                    log=lambda m: print(f"[bench] rank {rank}: {m}", file=sys.stderr, flush=True))
@@ -455,6 +518,7 @@ def main():
     done = torch.cuda.Event()
 
     last_sums = np.zeros(G._lib.NSUMS)                    # the totals of the latest step (N > 1: after the all-reduce)
+    first_contact_done = [False]
 
     def fence():
         torch.cuda.synchronize()
@@ -496,10 +560,16 @@ def main():
             return G.loglik_from_sums(host, n) if denom else G.loglik_z_from_sums(host, n)
         nonlocal guard
         ll = None
+        if guard is None and world > 1 and not first_contact_done[0]:
+            guard = arm_guard()                                   # every multi-rank backend: the first all-reduced evaluation
         if guard is not None:
+            stall = os.environ.get("GPV_BENCH_STALL_RANK")        # developer switch (tests): this rank sleeps before its
+            if stall is not None and int(stall) == rank:          # first evaluation, the others wait in the collective
+                time.sleep(float(os.environ.get("GPV_BENCH_STALL_S", "30")))
             step()                                                # first contact: the first all-reduced evaluation of the job
             guard.cancel()
             guard = None
+            first_contact_done[0] = True
         # like timeit: no cyclic-GC pass inside the timed region (with torch imported a full collection walks millions of
         # objects: one 55 ms pause was seen in a 70 ms region of 0.18 ms steps; tools/comm_diag.py).  Collected HERE, before the
         # clock warm-up: a collection between the warm-up and the timed steps idles the GPU for ~40 ms and the clock is down again
@@ -598,6 +668,15 @@ def main():
             locs, z, revNN, revCond, a, b = build_workload(n, m, d, 0, args.emulate_world, device=local_rank)
         else:
             locs, z, revNN, revCond, a, b = build_workload(n, m, d, rank, world, device=local_rank)
+            corrupt = os.environ.get("GPV_BENCH_CORRUPT", "")     # developer switch (tests of the self-check): "data:R" makes
+            if corrupt:                                           # rank R evaluate a wrong datum, "rows:R" makes it drop a row
+                kind, r_bad = corrupt.split(":")
+                if int(r_bad) == rank and kind == "data":
+                    z = z.copy()
+                    z[a] += 1.0
+                elif int(r_bad) == rank and kind == "rows":
+                    b -= 1
+                    revNN, revCond = revNN[:-1], revCond[:-1]
         plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
         plan.set_data(z)
         if comm is not None:
@@ -721,6 +800,7 @@ def main():
                     nlev = ps.build_posterior()
                     ts = time.time() - t0
                     el, km, ll = measure(ps, G.GPV_WANT_DENOM, True, args.steps, 2)
+                    sums_S, mu_S = ps.sums().copy(), None
                     sec["mode_S"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
                                      "sets_kernel_ms": km, "loglik": ll, "levels": nlev, "setup_s": round(ts, 2),
                                      "what": "the reference's defaults: ordering='maxmin', cond.yz='SGV'; set kernel + "
@@ -732,6 +812,7 @@ def main():
                         sec["mode_S_mean"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
                                               "sets_kernel_ms": km,
                                               "what": "mode_S plus the posterior mean of the latent field at the observed locations"}
+                        mu_S = ps.posterior_mean()
                     except Exception as e:
                         sec["mode_S_mean"] = {"error": repr(e)}
                     del ps
@@ -752,6 +833,11 @@ def main():
                         del pm
                     except Exception as e:
                         sec["mode_L_maxmin"] = {"error": repr(e)}
+                    if not args.no_cpu_baseline:
+                        try:
+                            sec["mode_S"]["parity_in_run"] = mode_S_oracle(va, z, covparms, tau, sec["mode_S"]["loglik"], sums_S, mu_S)
+                        except Exception as e:
+                            sec["mode_S"]["parity_in_run"] = {"error": repr(e)}
                     del va
                 except Exception as e:                       # never lose the headline line to a secondary failure
                     sec["mode_S"] = {"error": repr(e)}

@@ -33,8 +33,8 @@ _LIB = None
 # ----------------------------------------------------------------------------
 def build_c_oracle(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "u_nzentries_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("u_nzentries_oracle.c", "sparse_chol_oracle.c", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so"])
     return so
 
@@ -58,6 +58,14 @@ def _lib():
         _LIB.oracle_rows_extended.argtypes = [ctypes.c_int, ctypes.c_long, lp, ctypes.c_long, ctypes.c_int, ctypes.c_int,
                                               dp, lp, dp, dp, ctypes.c_int, dp, dp, dp]
         _LIB.oracle_long_double_digits.restype = ctypes.c_int
+        _LIB.oracle_sparse_chol_symbolic.restype = ctypes.c_long
+        _LIB.oracle_sparse_chol_symbolic.argtypes = [ctypes.c_long, lp, lp, lp, lp]
+        _LIB.oracle_sparse_chol_numeric.restype = ctypes.c_long
+        _LIB.oracle_sparse_chol_numeric.argtypes = [ctypes.c_long, lp, lp, dp, lp, lp, lp, dp]
+        _LIB.oracle_sparse_lsolve.restype = None
+        _LIB.oracle_sparse_lsolve.argtypes = [ctypes.c_long, lp, lp, dp, dp]
+        _LIB.oracle_sparse_ltsolve.restype = None
+        _LIB.oracle_sparse_ltsolve.argtypes = [ctypes.c_long, lp, lp, dp, dp]
     return _LIB
 
 
@@ -816,6 +824,200 @@ def vecchia_prediction_mean(z, va, covparms, nuggets, covmodel="matern", both=Fa
     U_obj = createU(va, covparms, nuggets, covmodel)                   # :25
     V = U2V(U_obj)                                                     # :28
     return vecchia_mean(z, U_obj, V, both)                             # :34
+
+
+# ----------------------------------------------------------------------------
+# The same R callers on SPARSE matrices, for sizes the dense restatements above cannot hold (n = 1e6): what the reference
+# itself does (Matrix::sparseMatrix, tcrossprod, chol, solve).  Pinned to the dense functions in tests/test_oracle.py.
+# ----------------------------------------------------------------------------
+def U_triplets_vectorised(revNN, revCond, obs):
+    """R/U_sparsity.R:19-73 without the loops: (rowpointers, colindices, latent_map, observed_map, size), 1-based, in the
+    order the literal U_sparsity above produces them (rows of revNNarray one after the other, valid entries left to
+    right, then the Z pairs)."""
+    revNN = np.asarray(revNN, dtype=np.float64)
+    revCond = np.asarray(revCond, dtype=np.float64)
+    obs = np.asarray(obs, dtype=bool)
+    nnp = revNN.shape[0]
+    n = int(obs.sum())
+    pos = np.arange(nnp, dtype=np.int64) + np.concatenate([[0], np.cumsum(obs)[:-1]])   # :19-29 y_k, then z_k if observed
+    latent_map = pos + 1
+    observed_map = np.where(obs, pos + 2, -1)
+    ok = ~np.isnan(revNN)
+    k_idx = np.nonzero(ok)[0]
+    inds0 = revNN[ok].astype(np.int64) - 1
+    rc = revCond[ok] == 1.0
+    coli = np.where(rc, latent_map[inds0], observed_map[inds0])         # :44-50
+    if np.any(coli < 0):                                                # observed_map is NA there: sparseMatrix() stops
+        raise ValueError("U_sparsity: a location without an observation is conditioned on as observed")
+    rowp = latent_map[k_idx]
+    ko = np.where(obs)[0]
+    Zrow = np.repeat(observed_map[ko], 2)                               # :59-69
+    Zcol = np.stack([latent_map[ko], observed_map[ko]], axis=1).reshape(-1)
+    return (np.concatenate([rowp, Zrow]), np.concatenate([coli, Zcol]), latent_map, observed_map, nnp + n)
+
+
+def createU_sparse(va, covparms, nuggets, covmodel="matern", U_entries=None):
+    """createU above with U as a scipy.sparse CSC matrix (R/createU.R:65-86,141-171; positive nuggets only: the
+    zero-nugget surgery of :173-193 stays with the dense restatement).  U_entries: a U_NZentries result to reuse."""
+    import scipy.sparse as sp
+    n = int(np.sum(va["obs"]))
+    prep = va["U_prep"]
+    revNN = np.asarray(prep["revNNarray"], dtype=np.float64)
+    revCond = np.asarray(prep["revCond"], dtype=np.float64)
+    rowp, coli, latent_map, _, size = U_triplets_vectorised(revNN, revCond, va["obs"])
+    latent = np.zeros(size, dtype=bool)
+    latent[latent_map - 1] = True
+    ord_ = va["ord"]
+    nug = np.asarray(nuggets, dtype=np.float64)
+    if nug.size == 1:                                               # :74
+        nug = np.repeat(nug, n)
+    if np.any(nug == 0):
+        raise ValueError("createU_sparse: zero nuggets are handled by the dense createU only")
+    nuggets_all = np.concatenate([nug, np.zeros(int(latent.sum()) - n)])   # :75
+    ord_all = np.concatenate([ord_[:n], ord_ + n]) if va["cond_yz"] == "zy" else ord_   # :76
+    nuggets_all_ord = nuggets_all[ord_all - 1]                      # :77
+    nuggets_ord = nuggets_all[va["ord_z"] - 1]                      # :78
+    if U_entries is None:
+        U_entries = U_NZentries(prep.get("n_cores", max_threads()), n, va["locsord"], np.nan_to_num(revNN, nan=0.0),
+                                revCond, nuggets_all_ord, nuggets_ord, covmodel, covparms)          # :146-154
+    L = np.ascontiguousarray(U_entries["Lentries"])
+    n0 = (~np.isnan(revNN)).sum(axis=1)
+    keep = np.arange(revNN.shape[1])[None, :] < n0[:, None]         # :158-159 first n0 entries of each row, row-major
+    vals = np.concatenate([L[keep], U_entries["Zentries"]])         # :160
+    U = sp.coo_matrix((vals, (coli - 1, rowp - 1)), shape=(size, size)).tocsc()   # :161-162 (duplicates are summed)
+    obs = np.asarray(va["obs"], dtype=bool)
+    if va["cond_yz"] == "zy":                                       # :166-171
+        keepd = np.ones(size, dtype=bool)
+        keepd[2 * np.arange(n)] = False
+        U = U[keepd][:, keepd].tocsc()
+        latent = latent[keepd]
+        obs = np.delete(obs, np.arange(n, 2 * n))
+    return dict(U=U, latent=latent, ord=ord_, obs=obs, ord_z=va["ord_z"], ord_pred=va["ord_pred"],
+                cond_yz=va["cond_yz"], ic0=va.get("ic0", False), U_entries=U_entries, zero_nugg={})
+
+
+def sparse_chol_lower(A):
+    """The lower Cholesky factor of a sparse symmetric positive definite matrix in the natural order, = t(Matrix::chol(A))
+    with Matrix's default pivot = FALSE (R/vecchia_prediction.R:80), through oracle/sparse_chol_oracle.c.
+    Returns a scipy.sparse CSC matrix whose columns hold the diagonal first, rows ascending."""
+    import scipy.sparse as sp
+    Au = sp.triu(A, format="csc")
+    Au.sort_indices()
+    n = Au.shape[0]
+    lp = ctypes.POINTER(ctypes.c_long)
+    Ap = np.ascontiguousarray(Au.indptr, dtype=np.int64)
+    Ai = np.ascontiguousarray(Au.indices, dtype=np.int64)
+    Ax = np.ascontiguousarray(Au.data, dtype=np.float64)
+    parent = np.empty(max(n, 1), dtype=np.int64)
+    cnt = np.empty(max(n, 1), dtype=np.int64)
+    P = lambda a: a.ctypes.data_as(lp)
+    nnz = _lib().oracle_sparse_chol_symbolic(n, P(Ap), P(Ai), P(parent), P(cnt))
+    if nnz < 0:
+        raise MemoryError("oracle_sparse_chol_symbolic")
+    Lp = np.concatenate([[0], np.cumsum(cnt[:n])]).astype(np.int64)
+    Li = np.empty(max(nnz, 1), dtype=np.int64)
+    Lx = np.empty(max(nnz, 1), dtype=np.float64)
+    st = _lib().oracle_sparse_chol_numeric(n, P(Ap), P(Ai), _dptr(Ax), P(parent), P(Lp), P(Li), _dptr(Lx))
+    if st != 0:
+        raise np.linalg.LinAlgError(f"sparse_chol_lower: pivot {st} is not positive")
+    return sp.csc_matrix((Lx[:nnz], Li[:nnz], Lp), shape=(n, n))
+
+
+def _tri_solve(V, b, transpose=False):
+    """Matrix::solve(V, b) / solve(t(V), b) for the lower-triangular CSC factor of sparse_chol_lower (or any lower
+    triangular CSC matrix: it is brought to the diagonal-first column layout)."""
+    import scipy.sparse as sp
+    V = sp.csc_matrix(V)
+    V.sort_indices()                                                # lower triangular + sorted rows => diagonal first
+    n = V.shape[0]
+    lp = ctypes.POINTER(ctypes.c_long)
+    Lp = np.ascontiguousarray(V.indptr, dtype=np.int64)
+    Li = np.ascontiguousarray(V.indices, dtype=np.int64)
+    Lx = np.ascontiguousarray(V.data, dtype=np.float64)
+    if n and not np.array_equal(Li[Lp[:-1]], np.arange(n)):
+        raise ValueError("_tri_solve: the matrix is not lower triangular with a full diagonal")
+    x = np.array(b, dtype=np.float64).copy()
+    fn = _lib().oracle_sparse_ltsolve if transpose else _lib().oracle_sparse_lsolve
+    fn(n, Lp.ctypes.data_as(lp), Li.ctypes.data_as(lp), _dptr(Lx), _dptr(x))
+    return x
+
+
+def _rev_sparse(M):
+    """revMat (R/vecchia_likelihood.R:103) of a sparse matrix."""
+    import scipy.sparse as sp
+    M = sp.coo_matrix(M)
+    return sp.coo_matrix((M.data, (M.shape[0] - 1 - M.row, M.shape[1] - 1 - M.col)), shape=M.shape).tocsc()
+
+
+def U2V_sparse(U_obj):
+    """U2V above on sparse matrices (R/vecchia_prediction.R:62-111, ic0 = FALSE): a lower-triangular CSC V.ord."""
+    import scipy.sparse as sp
+    if U_obj.get("ic0", False):
+        raise ValueError("U2V_sparse: ic0 = TRUE is restated densely only (ichol above)")
+    U = sp.csr_matrix(U_obj["U"])
+    latent = np.asarray(U_obj["latent"], dtype=bool)
+    Uy = U[np.where(latent)[0], :]                                      # :66
+    chol_rev = lambda A: sparse_chol_lower(_rev_sparse(A))
+    if U_obj["cond_yz"] == "zy":                                        # :68-70
+        return _rev_sparse(Uy.tocsc()[:, np.where(latent)[0]])
+    if U_obj["ord_pred"] != "obspred":                                  # :72-83
+        return chol_rev(Uy @ Uy.T)
+    last_obs = int(np.max(np.where(~latent)[0])) + 1                    # :87
+    latents_before = int(latent[:last_obs].sum())                       # :88
+    latents_after = int(latent[last_obs:].sum())                        # :89
+    V_pr = _rev_sparse(Uy.tocsc()[:, last_obs:])                        # :92
+    U_oo = Uy[:latents_before, :][:, :last_obs]                         # :95
+    V_oor = chol_rev(U_oo @ U_oo.T)                                     # :96-100
+    V_or = sp.vstack([sp.csc_matrix((latents_after, latents_before)), V_oor])   # :103-104
+    return sp.hstack([V_pr, V_or]).tocsc()                              # :106
+
+
+def vecchia_likelihood_U_sparse(z, U_obj, V=None, terms=False):
+    """vecchia_likelihood_U above on a sparse U (R/vecchia_likelihood.R:63-99).  With terms=True also returns
+    dict(logdet_num, quadform_num, logdet_denom, quadform_denom, V)."""
+    import scipy.sparse as sp
+    U = sp.csr_matrix(U_obj["U"])
+    latent = np.asarray(U_obj["latent"], dtype=bool)
+    zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]      # :68
+    const = np.sum(~latent) * np.log(2 * np.pi)                     # :71
+    z1 = U[np.where(~latent)[0], :].T @ zord                        # :74
+    quadform_num = float(np.sum(z1 ** 2))                           # :75
+    logdet_num = -2 * float(np.sum(np.log(U.diagonal())))           # :76
+    if latent.sum() == 0:                                           # :79-81
+        logdet_denom = quadform_denom = 0.0
+    else:
+        z2 = U[np.where(latent)[0], :] @ z1                         # :85-86
+        if V is None:
+            V = U2V_sparse(U_obj)                                   # :87
+        z3 = _tri_solve(V, z2[::-1])                                # :88
+        quadform_denom = float(np.sum(z3 ** 2))                     # :89
+        logdet_denom = -2 * float(np.sum(np.log(V.diagonal())))     # :90
+    neg2loglik = logdet_num - logdet_denom + quadform_num - quadform_denom + const   # :95
+    if terms:
+        return -neg2loglik / 2, dict(logdet_num=logdet_num, quadform_num=quadform_num, logdet_denom=logdet_denom,
+                                     quadform_denom=quadform_denom, V=V)
+    return -neg2loglik / 2                                          # :96
+
+
+def vecchia_mean_sparse(z, U_obj, V, both=False, ordered=False):
+    """vecchia_mean above on sparse matrices (R/vecchia_prediction.R:118-142); ordered=True returns mu.ord (:126)."""
+    import scipy.sparse as sp
+    U = sp.csr_matrix(U_obj["U"])
+    latent = np.asarray(U_obj["latent"], dtype=bool)
+    zord = np.asarray(z, dtype=np.float64)[U_obj["ord_z"] - 1]        # :121
+    z1 = U[np.where(~latent)[0], :].T @ zord                          # :122
+    z2 = U[np.where(latent)[0], :] @ z1                               # :123
+    temp = _tri_solve(V, z2[::-1])                                    # :124
+    mu_rev = -_tri_solve(V, temp, transpose=True)                     # :125
+    mu_ord = mu_rev[::-1]                                             # :126
+    if ordered:
+        return mu_ord
+    orig_order = np.argsort(U_obj["ord"], kind="stable")              # :135
+    mu = mu_ord[orig_order]                                           # :136
+    obs_orig = np.asarray(U_obj["obs"], dtype=bool)[orig_order]       # :137
+    if both:
+        return mu[obs_orig], mu[~obs_orig]                            # :138-139
+    return mu[obs_orig]
 
 
 def vl_family(model, likparms=None):

@@ -1,0 +1,94 @@
+"""The device posterior pass (U2V, denominator, vecchia_mean: SURVEY.md §8 row f-1) against the ORACLE at scale.
+
+The dense restatement `oracle.r_side.U2V` stops at n ~ 3000; here the sparse one (`createU_sparse`, `U2V_sparse`,
+`vecchia_likelihood_U_sparse`, `vecchia_mean_sparse`: Matrix::tcrossprod / chol / solve restated with scipy.sparse and the
+oracle's own natural-order sparse Cholesky, pinned to the dense functions in tests/test_oracle.py) meets the HIP pass
+directly at n = 6e4 (wide levels), at BASELINE config 5's n = 5e5 and at mode S's n = 1e6 (the reference's defaults:
+maxmin + SGV, R/vecchia_specify.R:83-96).  Nothing here compares the product with itself.
+
+Compared, all to 1e-8 relative: sums[2] = log det W = -logdet.denom (R/vecchia_likelihood.R:90), sums[3] =
+quadform.denom (:89), the numerator terms (:75-76), the log-likelihood (:95-96) and the posterior mean mu.obs
+(R/vecchia_prediction.R:118-142; absolute 1e-8 x max|mu|)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-8
+
+
+def _need_gpu():
+    import gpvecchia_amd as G
+    if G.device_count() < 1:
+        pytest.fail("gpu-marked test but libgpvecchia_hip sees no HIP device")
+    return G
+
+
+def _to_oracle_va(va):
+    prep = dict(va["U_prep"])
+    nn = prep["revNNarray"]
+    prep["revNNarray"] = np.where(nn == 0, np.nan, nn.astype(np.float64))
+    prep["revCond"] = np.where(prep["revCond"] < 0, np.nan, prep["revCond"].astype(np.float64))
+    out = {k: v for k, v in va.items() if not isinstance(k, tuple)}
+    out["U_prep"] = prep
+    return out
+
+
+def _compare(G, locs, z, m, cp, tau, min_levels):
+    from gpvecchia_amd import api as A
+    from oracle import r_side as R
+    n = locs.shape[0]
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+    ll = G.vecchia_likelihood(z, va, cp, tau)
+    plan = va[("_plan", 0)]
+    assert plan.has_posterior and plan.posterior_levels() >= min_levels
+    sums = plan.sums().copy()
+    mu = G.vecchia_prediction(z, va, cp, tau)["mu_obs"]
+    # the oracle: its own U entries (C restatement), its own sparse U, W, Cholesky and solves
+    Us = R.createU_sparse(_to_oracle_va(va), cp, tau)
+    V = R.U2V_sparse(Us)
+    ll_ref, t = R.vecchia_likelihood_U_sparse(z, Us, V=V, terms=True)
+    mu_ref = R.vecchia_mean_sparse(z, Us, V)
+    logdet_num, quadform_num = A.numerator_from_sums(sums)
+    assert abs(logdet_num - t["logdet_num"]) <= RTOL * abs(t["logdet_num"])
+    assert abs(quadform_num - t["quadform_num"]) <= RTOL * abs(t["quadform_num"])
+    assert abs(sums[2] + t["logdet_denom"]) <= RTOL * abs(t["logdet_denom"]), (sums[2], t["logdet_denom"])
+    assert abs(sums[3] - t["quadform_denom"]) <= RTOL * abs(t["quadform_denom"]), (sums[3], t["quadform_denom"])
+    assert abs(ll - ll_ref) <= RTOL * abs(ll_ref), (ll, ll_ref)
+    assert mu.shape == mu_ref.shape == (n,)
+    np.testing.assert_allclose(mu, mu_ref, rtol=0, atol=RTOL * max(1.0, np.abs(mu_ref).max()))
+    return dict(ll=ll, ll_ref=ll_ref, nnzV=int(V.nnz), levels=plan.posterior_levels())
+
+
+def test_posterior_pass_against_sparse_oracle_n6e4():
+    """n = 6e4, m = 20, vector nuggets: the schedule has one-wave-per-column wide levels, narrow levels, the leaf level
+    and the dense top block."""
+    G = _need_gpu()
+    n, m = 60_000, 20
+    rng = np.random.default_rng(5)
+    locs = rng.random((n, 2)); z = rng.standard_normal(n)
+    tau = 0.1 + 0.1 * rng.random(n)
+    _compare(G, locs, z, m, [1.2, 0.01, 1.5], tau, 20)
+
+
+def test_posterior_pass_against_sparse_oracle_C5_n5e5_m30():
+    """BASELINE config 5's size and covariance (n = 5e5, m = 30, range 0.03), with the kind of nuggets a Vecchia-Laplace
+    Newton step hands down: pseudo-data and pseudo-variances D = exp(-y) of a Poisson model at a smooth y
+    (R/vecchia_laplace_NR.R:93-113)."""
+    G = _need_gpu()
+    n, m = 500_000, 30
+    locs = np.random.default_rng(0).random((n, 2))
+    y = 1.0 + np.sin(2 * np.pi * locs[:, 0]) * np.cos(2 * np.pi * locs[:, 1])
+    zc = np.random.default_rng(2).poisson(np.exp(y)).astype(float)
+    D = np.exp(-y)
+    pseudo = D * (zc - np.exp(y)) + y
+    _compare(G, locs, pseudo, m, [0.5, 0.03, 1.5], D, 40)
+
+
+def test_posterior_pass_against_sparse_oracle_modeS_n1e6_m30():
+    """bench.py --mode S's workload: n = 1e6, m = 30, maxmin + SGV, Matern 1.5 with range 0.02, nugget 0.1."""
+    G = _need_gpu()
+    n, m = 1_000_000, 30
+    locs = np.random.default_rng(0).random((n, 2))
+    z = np.random.default_rng(1).standard_normal(n)
+    _compare(G, locs, z, m, [1.0, 0.02, 1.5], 0.1, 60)

@@ -334,3 +334,69 @@ def test_check_rows_adjudicates_against_extended_precision():
     off[40, 2] *= 1 + 1e-6
     res = check_rows(ex, off, va["locsord"], prep["revNNarray"], prep["revCond"], 0.1, "matern", cp)
     assert res["escaped"] == 1
+
+
+def test_sparse_cholesky_of_the_oracle_equals_dense_cholesky():
+    """oracle/sparse_chol_oracle.c (natural-order up-looking Cholesky = t(Matrix::chol(., pivot = FALSE))) against numpy on
+    random sparse SPD matrices with fill, a diagonal matrix, a 1 x 1 matrix; a non-positive pivot is reported."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    for n, dens in [(1, 1.0), (7, 0.5), (60, 0.08), (200, 0.02), (150, 0.0)]:
+        B = sp.random(n, n, density=dens, random_state=rng.integers(1 << 30), format="csc")
+        A = (B @ B.T + sp.diags(1.0 + rng.random(n))).tocsc()
+        Lw = R.sparse_chol_lower(A)
+        Ld = np.linalg.cholesky(A.toarray())
+        np.testing.assert_allclose(Lw.toarray(), Ld, rtol=0, atol=1e-13 * np.abs(Ld).max())
+        assert np.array_equal(Lw.indices[Lw.indptr[:-1]], np.arange(n))           # diagonal first in every column
+        b = rng.standard_normal(n)
+        np.testing.assert_allclose(R._tri_solve(Lw, b), np.linalg.solve(Ld, b), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(R._tri_solve(Lw, b, transpose=True), np.linalg.solve(Ld.T, b), rtol=1e-10, atol=1e-12)
+    A = sp.csc_matrix(np.array([[4.0, 2.0, 0.0], [2.0, 1.0, 0.0], [0.0, 0.0, 1.0]]))   # singular leading 2 x 2 block
+    with pytest.raises(np.linalg.LinAlgError):
+        R.sparse_chol_lower(A)
+
+
+@pytest.mark.parametrize("cond,pred,ordering_pred", [("SGV", False, None), ("y", False, None), ("z", False, None),
+                                                    ("zy", False, None), ("y", True, "general"),
+                                                    ("SGV", True, "obspred"), ("y", True, "obspred"),
+                                                    ("zy", True, "obspred"), ("SGVT", True, "obspred")])
+def test_sparse_r_side_equals_the_dense_restatement(cond, pred, ordering_pred):
+    """U_triplets_vectorised / createU_sparse / U2V_sparse / vecchia_likelihood_U_sparse / vecchia_mean_sparse (what the
+    GPU tests use at n = 1e6) against the literal dense restatements of the same R functions, all three branches of U2V
+    (R/vecchia_prediction.R:68-70, :72-83, :84-107)."""
+    rng = np.random.default_rng(17)
+    n, m = 260, 8
+    locs = rng.random((n, 2))
+    z = rng.standard_normal(n)
+    tau = 0.05 + 0.2 * rng.random(n)
+    cp = [1.3, 0.15, 1.5]
+    kw = dict(locs_pred=rng.random((40, 2)), ordering_pred=ordering_pred) if pred else {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        va = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond, **kw)
+    prep = va["U_prep"]
+    rp, ci, lat, obsmap, size = R.U_triplets_vectorised(prep["revNNarray"], prep["revCond"], va["obs"])
+    assert size == prep["size"]
+    assert np.array_equal(rp, prep["rowpointers"]) and np.array_equal(ci, prep["colindices"])
+    assert np.array_equal(lat, prep["y_ind"]) and np.array_equal(obsmap, prep["observed_map"])
+    Ud = R.createU(va, cp, tau)
+    Us = R.createU_sparse(va, cp, tau)
+    assert np.array_equal(Us["U"].toarray(), Ud["U"])
+    assert np.array_equal(Us["latent"], Ud["latent"]) and np.array_equal(Us["obs"], Ud["obs"])
+    Vd = R.U2V(Ud)
+    Vs = R.U2V_sparse(Us)
+    np.testing.assert_allclose(Vs.toarray(), Vd, rtol=0, atol=1e-12 * np.abs(Vd).max())
+    ll_d = R.vecchia_likelihood_U(z, Ud)
+    ll_s, t = R.vecchia_likelihood_U_sparse(z, Us, terms=True)
+    assert abs(ll_s - ll_d) <= 1e-12 * abs(ll_d)
+    if cond != "z":
+        assert abs(t["logdet_denom"] + 2 * np.sum(np.log(np.diag(Vd)))) <= 1e-11 * abs(t["logdet_denom"])
+    mo_d, mp_d = R.vecchia_mean(z, Ud, Vd, both=True)
+    mo_s, mp_s = R.vecchia_mean_sparse(z, Us, Vs, both=True)
+    np.testing.assert_allclose(mo_s, mo_d, rtol=0, atol=1e-11 * np.abs(mo_d).max())
+    if pred:
+        np.testing.assert_allclose(mp_s, mp_d, rtol=0, atol=1e-11 * np.abs(mo_d).max())
+    if cond == "SGV" and not pred:                                       # no fill under SGV (SURVEY §8f-1)
+        B = Us["U"].tocsr()[np.where(Us["latent"])[0], :][:, np.where(Us["latent"])[0]]
+        assert Vs.nnz == B.nnz
