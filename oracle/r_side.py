@@ -66,6 +66,13 @@ def _lib():
         _LIB.oracle_sparse_lsolve.argtypes = [ctypes.c_long, lp, lp, dp, dp]
         _LIB.oracle_sparse_ltsolve.restype = None
         _LIB.oracle_sparse_ltsolve.argtypes = [ctypes.c_long, lp, lp, dp, dp]
+        ldp = ctypes.POINTER(ctypes.c_longdouble)
+        _LIB.oracle_sparse_chol_numeric_ld.restype = ctypes.c_long
+        _LIB.oracle_sparse_chol_numeric_ld.argtypes = [ctypes.c_long, lp, lp, ldp, lp, lp, lp, ldp]
+        _LIB.oracle_sparse_lsolve_ld.restype = None
+        _LIB.oracle_sparse_lsolve_ld.argtypes = [ctypes.c_long, lp, lp, ldp, ldp]
+        _LIB.oracle_sparse_ltsolve_ld.restype = None
+        _LIB.oracle_sparse_ltsolve_ld.argtypes = [ctypes.c_long, lp, lp, ldp, ldp]
     return _LIB
 
 
@@ -907,7 +914,10 @@ def sparse_chol_lower(A):
     lp = ctypes.POINTER(ctypes.c_long)
     Ap = np.ascontiguousarray(Au.indptr, dtype=np.int64)
     Ai = np.ascontiguousarray(Au.indices, dtype=np.int64)
-    Ax = np.ascontiguousarray(Au.data, dtype=np.float64)
+    ext = Au.dtype == np.longdouble                                 # the adjudicator's instance (x87 extended precision)
+    real = np.longdouble if ext else np.float64
+    rp = (lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_longdouble))) if ext else _dptr
+    Ax = np.ascontiguousarray(Au.data, dtype=real)
     parent = np.empty(max(n, 1), dtype=np.int64)
     cnt = np.empty(max(n, 1), dtype=np.int64)
     P = lambda a: a.ctypes.data_as(lp)
@@ -916,8 +926,9 @@ def sparse_chol_lower(A):
         raise MemoryError("oracle_sparse_chol_symbolic")
     Lp = np.concatenate([[0], np.cumsum(cnt[:n])]).astype(np.int64)
     Li = np.empty(max(nnz, 1), dtype=np.int64)
-    Lx = np.empty(max(nnz, 1), dtype=np.float64)
-    st = _lib().oracle_sparse_chol_numeric(n, P(Ap), P(Ai), _dptr(Ax), P(parent), P(Lp), P(Li), _dptr(Lx))
+    Lx = np.empty(max(nnz, 1), dtype=real)
+    fn = _lib().oracle_sparse_chol_numeric_ld if ext else _lib().oracle_sparse_chol_numeric
+    st = fn(n, P(Ap), P(Ai), rp(Ax), P(parent), P(Lp), P(Li), rp(Lx))
     if st != 0:
         raise np.linalg.LinAlgError(f"sparse_chol_lower: pivot {st} is not positive")
     return sp.csc_matrix((Lx[:nnz], Li[:nnz], Lp), shape=(n, n))
@@ -933,12 +944,18 @@ def _tri_solve(V, b, transpose=False):
     lp = ctypes.POINTER(ctypes.c_long)
     Lp = np.ascontiguousarray(V.indptr, dtype=np.int64)
     Li = np.ascontiguousarray(V.indices, dtype=np.int64)
-    Lx = np.ascontiguousarray(V.data, dtype=np.float64)
+    ext = V.dtype == np.longdouble
+    real = np.longdouble if ext else np.float64
+    rp = (lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_longdouble))) if ext else _dptr
+    Lx = np.ascontiguousarray(V.data, dtype=real)
     if n and not np.array_equal(Li[Lp[:-1]], np.arange(n)):
         raise ValueError("_tri_solve: the matrix is not lower triangular with a full diagonal")
-    x = np.array(b, dtype=np.float64).copy()
-    fn = _lib().oracle_sparse_ltsolve if transpose else _lib().oracle_sparse_lsolve
-    fn(n, Lp.ctypes.data_as(lp), Li.ctypes.data_as(lp), _dptr(Lx), _dptr(x))
+    x = np.array(b, dtype=real).copy()
+    if ext:
+        fn = _lib().oracle_sparse_ltsolve_ld if transpose else _lib().oracle_sparse_lsolve_ld
+    else:
+        fn = _lib().oracle_sparse_ltsolve if transpose else _lib().oracle_sparse_lsolve
+    fn(n, Lp.ctypes.data_as(lp), Li.ctypes.data_as(lp), rp(Lx), rp(x))
     return x
 
 
@@ -1018,6 +1035,48 @@ def vecchia_mean_sparse(z, U_obj, V, both=False, ordered=False):
     if both:
         return mu[obs_orig], mu[~obs_orig]                            # :138-139
     return mu[obs_orig]
+
+
+def posterior_extended(z, va, covparms, nuggets, covmodel="matern"):
+    """The adjudicator for the posterior pass: the chain createU -> U2V -> vecchia_likelihood_U / vecchia_mean
+    (R/createU.R:141-171, R/vecchia_prediction.R:62-83,118-126, R/vecchia_likelihood.R:63-99; general ordering, positive
+    nuggets, cond.yz != 'zy') in x87 extended precision: U entries from rows_extended (rounded to double: 1e-16), W = U_y
+    U_y^T, the Cholesky factor, both triangular solves and every sum in long double.  Exact for the given inputs to
+    ~cond(W) * 1e-19.  Returns dict(mu_ord, loglik, logdet_num, quadform_num, logdet_denom, quadform_denom) as doubles."""
+    import scipy.sparse as sp
+    ld = np.longdouble
+    prep = va["U_prep"]
+    n = int(np.sum(va["obs"]))
+    if va["cond_yz"] == "zy" or va["ord_pred"] == "obspred" or n != va["locsord"].shape[0]:
+        raise ValueError("posterior_extended: plans without prediction locations, cond.yz in {'SGV','y','z'}")
+    nug = np.asarray(nuggets, dtype=np.float64)
+    if nug.size == 1:
+        nug = np.repeat(nug, n)
+    nuggets_ord = nug[va["ord_z"] - 1]
+    Nl = va["locsord"].shape[0]
+    Lx = rows_extended(np.arange(Nl), va["locsord"], prep["revNNarray"], prep["revCond"], nug[va["ord"] - 1], covmodel,
+                       covparms)
+    with np.errstate(divide="ignore"):
+        zd = (1.0 / np.sqrt(nuggets_ord.astype(ld)))
+    Zx = np.stack([-zd, zd], axis=1).reshape(-1).astype(np.float64)     # src/U_NZentries.cpp:111-115
+    Us = createU_sparse(va, covparms, nuggets, covmodel, U_entries=dict(Lentries=Lx, Zentries=Zx))
+    U = sp.csr_matrix(Us["U"]).astype(ld)
+    latent = np.asarray(Us["latent"], dtype=bool)
+    zord = np.asarray(z, dtype=np.float64)[va["ord_z"] - 1].astype(ld)
+    z1 = U[np.where(~latent)[0], :].T @ zord
+    quadform_num = np.sum(z1 * z1)
+    logdet_num = -2 * np.sum(np.log(U.diagonal()))
+    Uy = U[np.where(latent)[0], :]
+    z2 = Uy @ z1
+    V = sparse_chol_lower(_rev_sparse(Uy @ Uy.T))
+    z3 = _tri_solve(V, z2[::-1])
+    quadform_denom = np.sum(z3 * z3)
+    logdet_denom = -2 * np.sum(np.log(V.diagonal()))
+    mu_ord = (-_tri_solve(V, z3, transpose=True))[::-1]
+    const = ld(n) * np.log(2 * ld(np.pi))
+    ll = -(logdet_num - logdet_denom + quadform_num - quadform_denom + const) / 2
+    return dict(mu_ord=mu_ord.astype(np.float64), loglik=float(ll), logdet_num=float(logdet_num),
+                quadform_num=float(quadform_num), logdet_denom=float(logdet_denom), quadform_denom=float(quadform_denom))
 
 
 def vl_family(model, likparms=None):

@@ -85,62 +85,67 @@ long oracle_sparse_chol_symbolic(long n, const long *Ap, const long *Ai, long *p
 
 /* Numeric up-looking Cholesky.  Lp[n+1] must hold the column pointers (prefix sums of colcount), Li / Lx sized nnz(L).
  * Returns 0, or k+1 when the k-th pivot is not positive (the factorisation stops there, like CHOLMOD's "not positive
- * definite" error which Matrix::chol turns into an R error). */
-long oracle_sparse_chol_numeric(long n, const long *Ap, const long *Ai, const double *Ax, const long *parent,
-                                const long *Lp, long *Li, double *Lx)
-{
-    long *stack = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
-    long *path = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
-    long *flag = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));
-    long *fill = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));     /* next free slot of every column */
-    double *x = (double *)calloc((size_t)(n > 0 ? n : 1), sizeof(double));
-    long status = 0;
-    if (!stack || !path || !flag || !fill || !x) { status = -1; goto done; }
-    for (long k = 0; k < n; ++k) { flag[k] = -1; fill[k] = Lp[k]; }
-    for (long k = 0; k < n; ++k) {
-        long top = spo_reach(n, Ap, Ai, k, parent, stack, path, flag);
-        double d = 0.0;
-        for (long p = Ap[k]; p < Ap[k + 1]; ++p) {         /* scatter column k of the upper triangle */
-            long i = Ai[p];
-            if (i < k) x[i] = Ax[p];
-            else if (i == k) d = Ax[p];
-        }
-        for (long t = top; t < n; ++t) {                   /* L(0:k-1,0:k-1) y = A(0:k-1,k), y = row k of L */
-            long i = stack[t];
-            double lki = x[i] / Lx[Lp[i]];                  /* diagonal is the first entry of column i */
-            x[i] = 0.0;
-            for (long p = Lp[i] + 1; p < fill[i]; ++p) x[Li[p]] -= Lx[p] * lki;
-            d -= lki * lki;
-            long q = fill[i]++;
-            Li[q] = k;
-            Lx[q] = lki;
-        }
-        if (!(d > 0.0)) { status = k + 1; goto done; }
-        long q = fill[k]++;
-        Li[q] = k;
-        Lx[q] = sqrt(d);
-    }
-done:
-    free(stack); free(path); free(flag); free(fill); free(x);
-    return status;
+ * definite" error which Matrix::chol turns into an R error).
+ * Two instances of the numeric routines: double (the oracle proper) and x87 long double (the adjudicator of
+ * tests/: the same factorisation to ~cond * 1e-19, against which both the oracle's and the HIP path's posterior means
+ * are measured where they differ by more than the flat tolerance). */
+#define SPO_DEFINE(REAL, SUF, SQRT)                                                                                    \
+long oracle_sparse_chol_numeric##SUF(long n, const long *Ap, const long *Ai, const REAL *Ax, const long *parent,       \
+                                     const long *Lp, long *Li, REAL *Lx)                                               \
+{                                                                                                                      \
+    long *stack = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));                                              \
+    long *path = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));                                               \
+    long *flag = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));                                               \
+    long *fill = (long *)malloc(sizeof(long) * (size_t)(n > 0 ? n : 1));     /* next free slot of every column */       \
+    REAL *x = (REAL *)calloc((size_t)(n > 0 ? n : 1), sizeof(REAL));                                                   \
+    long status = 0;                                                                                                   \
+    if (!stack || !path || !flag || !fill || !x) { status = -1; goto done; }                                           \
+    for (long k = 0; k < n; ++k) { flag[k] = -1; fill[k] = Lp[k]; }                                                    \
+    for (long k = 0; k < n; ++k) {                                                                                     \
+        long top = spo_reach(n, Ap, Ai, k, parent, stack, path, flag);                                                 \
+        REAL d = 0;                                                                                                    \
+        for (long p = Ap[k]; p < Ap[k + 1]; ++p) {         /* scatter column k of the upper triangle */                \
+            long i = Ai[p];                                                                                            \
+            if (i < k) x[i] = Ax[p];                                                                                   \
+            else if (i == k) d = Ax[p];                                                                                \
+        }                                                                                                              \
+        for (long t = top; t < n; ++t) {                   /* L(0:k-1,0:k-1) y = A(0:k-1,k), y = row k of L */          \
+            long i = stack[t];                                                                                         \
+            REAL lki = x[i] / Lx[Lp[i]];                    /* diagonal is the first entry of column i */               \
+            x[i] = 0;                                                                                                  \
+            for (long p = Lp[i] + 1; p < fill[i]; ++p) x[Li[p]] -= Lx[p] * lki;                                        \
+            d -= lki * lki;                                                                                            \
+            long q = fill[i]++;                                                                                        \
+            Li[q] = k;                                                                                                 \
+            Lx[q] = lki;                                                                                               \
+        }                                                                                                              \
+        if (!(d > 0)) { status = k + 1; goto done; }                                                                   \
+        long q = fill[k]++;                                                                                            \
+        Li[q] = k;                                                                                                     \
+        Lx[q] = SQRT(d);                                                                                               \
+    }                                                                                                                  \
+done:                                                                                                                  \
+    free(stack); free(path); free(flag); free(fill); free(x);                                                          \
+    return status;                                                                                                     \
+}                                                                                                                      \
+/* x <- L^{-1} x (CSC lower triangular, diagonal first in every column) */                                             \
+void oracle_sparse_lsolve##SUF(long n, const long *Lp, const long *Li, const REAL *Lx, REAL *x)                        \
+{                                                                                                                      \
+    for (long j = 0; j < n; ++j) {                                                                                     \
+        x[j] /= Lx[Lp[j]];                                                                                             \
+        const REAL xj = x[j];                                                                                          \
+        for (long p = Lp[j] + 1; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;                                           \
+    }                                                                                                                  \
+}                                                                                                                      \
+/* x <- L^{-T} x */                                                                                                    \
+void oracle_sparse_ltsolve##SUF(long n, const long *Lp, const long *Li, const REAL *Lx, REAL *x)                       \
+{                                                                                                                      \
+    for (long j = n - 1; j >= 0; --j) {                                                                                \
+        REAL s = x[j];                                                                                                 \
+        for (long p = Lp[j] + 1; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];                                            \
+        x[j] = s / Lx[Lp[j]];                                                                                          \
+    }                                                                                                                  \
 }
 
-/* x <- L^{-1} x (CSC lower triangular, diagonal first in every column) */
-void oracle_sparse_lsolve(long n, const long *Lp, const long *Li, const double *Lx, double *x)
-{
-    for (long j = 0; j < n; ++j) {
-        x[j] /= Lx[Lp[j]];
-        const double xj = x[j];
-        for (long p = Lp[j] + 1; p < Lp[j + 1]; ++p) x[Li[p]] -= Lx[p] * xj;
-    }
-}
-
-/* x <- L^{-T} x */
-void oracle_sparse_ltsolve(long n, const long *Lp, const long *Li, const double *Lx, double *x)
-{
-    for (long j = n - 1; j >= 0; --j) {
-        double s = x[j];
-        for (long p = Lp[j] + 1; p < Lp[j + 1]; ++p) s -= Lx[p] * x[Li[p]];
-        x[j] = s / Lx[Lp[j]];
-    }
-}
+SPO_DEFINE(double, , sqrt)
+SPO_DEFINE(long double, _ld, sqrtl)

@@ -8,7 +8,12 @@ maxmin + SGV, R/vecchia_specify.R:83-96).  Nothing here compares the product wit
 
 Compared, all to 1e-8 relative: sums[2] = log det W = -logdet.denom (R/vecchia_likelihood.R:90), sums[3] =
 quadform.denom (:89), the numerator terms (:75-76), the log-likelihood (:95-96) and the posterior mean mu.obs
-(R/vecchia_prediction.R:118-142; absolute 1e-8 x max|mu|)."""
+(R/vecchia_prediction.R:118-142; max|d mu| <= 1e-8 x max|mu|).
+
+The posterior mean is a solve with W: two double-precision implementations may differ by cond(W) x 1e-16.  Where they differ
+by more than the flat 1e-8 the same rule as for the U entries applies (tests/_parity.py): both are measured against the
+chain evaluated in x87 extended precision (`oracle.r_side.posterior_extended`, pinned to 40-digit mpmath in
+tests/test_oracle.py) and the HIP path passes when its error is at most 4 x the oracle's own (or 1e-8)."""
 import numpy as np
 import pytest
 
@@ -56,8 +61,21 @@ def _compare(G, locs, z, m, cp, tau, min_levels):
     assert abs(sums[3] - t["quadform_denom"]) <= RTOL * abs(t["quadform_denom"]), (sums[3], t["quadform_denom"])
     assert abs(ll - ll_ref) <= RTOL * abs(ll_ref), (ll, ll_ref)
     assert mu.shape == mu_ref.shape == (n,)
-    np.testing.assert_allclose(mu, mu_ref, rtol=0, atol=RTOL * max(1.0, np.abs(mu_ref).max()))
-    return dict(ll=ll, ll_ref=ll_ref, nnzV=int(V.nnz), levels=plan.posterior_levels())
+    scale = max(1.0, np.abs(mu_ref).max())
+    diff = np.abs(mu - mu_ref).max() / scale
+    res = dict(ll=ll, ll_ref=ll_ref, nnzV=int(V.nnz), levels=plan.posterior_levels(), mu_diff=diff, adjudicated=False)
+    if not diff <= RTOL:
+        # beyond the flat tolerance: whose error is it?  Both against the extended-precision chain
+        ex = R.posterior_extended(z, _to_oracle_va(va), cp, tau)
+        mu_ext = np.empty(n)
+        mu_ext[va["ord"] - 1] = ex["mu_ord"]
+        err_hip = np.abs(mu - mu_ext).max() / scale
+        err_or = np.abs(mu_ref - mu_ext).max() / scale
+        res.update(adjudicated=True, err_hip=err_hip, err_oracle=err_or)
+        assert err_hip <= max(4.0 * err_or, RTOL), res
+        assert abs(ll - ex["loglik"]) <= RTOL * abs(ex["loglik"])
+    print("posterior-vs-oracle", res)
+    return res
 
 
 def test_posterior_pass_against_sparse_oracle_n6e4():
@@ -68,7 +86,8 @@ def test_posterior_pass_against_sparse_oracle_n6e4():
     rng = np.random.default_rng(5)
     locs = rng.random((n, 2)); z = rng.standard_normal(n)
     tau = 0.1 + 0.1 * rng.random(n)
-    _compare(G, locs, z, m, [1.2, 0.01, 1.5], tau, 20)
+    res = _compare(G, locs, z, m, [1.2, 0.01, 1.5], tau, 20)
+    assert not res["adjudicated"]                                    # a well-conditioned case: flat 1e-8 throughout
 
 
 def test_posterior_pass_against_sparse_oracle_C5_n5e5_m30():
@@ -91,4 +110,5 @@ def test_posterior_pass_against_sparse_oracle_modeS_n1e6_m30():
     n, m = 1_000_000, 30
     locs = np.random.default_rng(0).random((n, 2))
     z = np.random.default_rng(1).standard_normal(n)
-    _compare(G, locs, z, m, [1.0, 0.02, 1.5], 0.1, 60)
+    res = _compare(G, locs, z, m, [1.0, 0.02, 1.5], 0.1, 60)
+    assert not res["adjudicated"]

@@ -400,3 +400,68 @@ def test_sparse_r_side_equals_the_dense_restatement(cond, pred, ordering_pred):
     if cond == "SGV" and not pred:                                       # no fill under SGV
         B = Us["U"].tocsr()[np.where(Us["latent"])[0], :][:, np.where(Us["latent"])[0]]
         assert Vs.nnz == B.nnz
+
+
+def test_posterior_extended_agrees_with_mpmath_and_brackets_the_double_chain():
+    """oracle.r_side.posterior_extended (the adjudicator of tests/test_gpu_posterior_oracle.py: createU -> U2V -> likelihood
+    and posterior mean in x87 extended precision) against the same chain in 40-digit mpmath on an ill-conditioned case
+    (all-latent conditioning, range 0.6); the double-precision chain's error against it is orders of magnitude larger."""
+    import mpmath as mp
+    rng = np.random.default_rng(8)
+    n, m = 48, 6
+    locs = rng.random((n, 2))
+    z = rng.standard_normal(n)
+    tau = 0.02 + 0.05 * rng.random(n)
+    cp = [1.0, 0.6, 1.5]
+    va = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="y")
+    ex = R.posterior_extended(z, va, cp, tau)
+    prep = va["U_prep"]
+    lo = va["locsord"]
+    tau_o = tau[va["ord"] - 1]
+    with mp.workdps(40):
+        s3 = mp.sqrt(3)
+        size = prep["size"]
+        U = mp.zeros(size, size)
+        ymap, zmap = prep["y_ind"] - 1, prep["observed_map"] - 1
+        for k in range(n):
+            ok = ~np.isnan(prep["revNNarray"][k])
+            J = prep["revNNarray"][k, ok].astype(int) - 1
+            c = prep["revCond"][k, ok]
+            n0 = len(J)
+            S = mp.zeros(n0, n0)
+            for a in range(n0):
+                for b in range(n0):
+                    d = mp.sqrt(sum((mp.mpf(float(lo[J[a], t])) - mp.mpf(float(lo[J[b], t]))) ** 2 for t in range(2)))
+                    s = d / mp.mpf(cp[1])
+                    S[a, b] = mp.mpf(cp[0]) * (1 + s3 * s) * mp.exp(-s3 * s)
+                S[a, a] += mp.mpf(float(tau_o[J[a]])) * (1 - int(c[a]))
+            Lc = mp.cholesky(S)                                        # S = Lc Lc^T, R = Lc^T upper
+            e = mp.zeros(n0, 1); e[n0 - 1] = 1
+            M = mp.lu_solve(Lc.T, e)
+            for a in range(n0):
+                U[(ymap[J[a]] if c[a] == 1 else zmap[J[a]]), ymap[k]] += M[a]
+            U[ymap[k], zmap[k]] = -1 / mp.sqrt(mp.mpf(float(tau_o[k])))
+            U[zmap[k], zmap[k]] = 1 / mp.sqrt(mp.mpf(float(tau_o[k])))
+        zord = mp.matrix([float(v) for v in z[va["ord_z"] - 1]])
+        Uz = mp.matrix([[U[int(i), j] for j in range(size)] for i in zmap])
+        Uy = mp.matrix([[U[int(i), j] for j in range(size)] for i in ymap])
+        z1 = Uz.T * zord
+        z2 = Uy * z1
+        W = Uy * Uy.T
+        mu = -mp.lu_solve(W, z2)
+        Lw = mp.cholesky(W)
+        logdet_W = 2 * sum(mp.log(Lw[i, i]) for i in range(n))
+        quad_denom = (z2.T * mp.lu_solve(W, z2))[0]
+        ll = -(-2 * sum(mp.log(U[i, i]) for i in range(size)) + logdet_W + sum(v ** 2 for v in z1) - quad_denom
+               + n * mp.log(2 * mp.pi)) / 2
+        mu_mp = np.array([float(v) for v in mu])
+        ll_mp, ld_mp, qd_mp = float(ll), float(-logdet_W), float(quad_denom)
+    scale = np.abs(mu_mp).max()
+    err_ext = np.abs(ex["mu_ord"] - mu_mp).max() / scale
+    assert err_ext < 1e-13, err_ext
+    assert abs(ex["loglik"] - ll_mp) <= 1e-14 * abs(ll_mp)
+    assert abs(ex["logdet_denom"] - ld_mp) <= 1e-14 * abs(ld_mp) and abs(ex["quadform_denom"] - qd_mp) <= 1e-13 * abs(qd_mp)
+    Us = R.createU_sparse(va, cp, tau)
+    mu_d = R.vecchia_mean_sparse(z, Us, R.U2V_sparse(Us), ordered=True)
+    err_dbl = np.abs(mu_d - mu_mp).max() / scale
+    assert err_dbl > 20 * err_ext                                      # the adjudicator is the better of the two by far
