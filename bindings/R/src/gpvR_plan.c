@@ -38,6 +38,13 @@ static gpv_plan *gpvR_get(SEXP xp)
     return pl;
 }
 
+/* the plan's own shape: every length below is checked against it, no output is sized from an R argument */
+static void gpvR_dims(gpv_plan *pl, int64_t *Nlocs, int *p)
+{
+    int d = 0;
+    gpvR_fail(gpv_plan_dims(pl, Nlocs, &d, p), "gpv_plan_dims");
+}
+
 static void gpvR_finalize(SEXP xp)
 {
     gpv_plan *pl = (gpv_plan *)R_ExternalPtrAddr(xp);
@@ -92,18 +99,31 @@ SEXP gpvR_plan_destroy(SEXP xp)
 /* z[ord.z] (R/vecchia_likelihood.R:68), length Nlocs */
 SEXP gpvR_plan_set_data(SEXP xp, SEXP zord)
 {
+    gpv_plan *pl = gpvR_get(xp);
+    int64_t Nlocs = 0;
+    int p = 0;
+    gpvR_dims(pl, &Nlocs, &p);
     if (!Rf_isReal(zord)) Rf_error("z must be double");
-    gpvR_fail(gpv_plan_set_data(gpvR_get(xp), REAL(zord)), "gpv_plan_set_data");
+    if ((int64_t)XLENGTH(zord) != Nlocs) Rf_error("z has length %.0f, the plan has %.0f locations", (double)XLENGTH(zord), (double)Nlocs);
+    gpvR_fail(gpv_plan_set_data(pl, REAL(zord)), "gpv_plan_set_data");
     return R_NilValue;
 }
 
 /* once per plan, for cond.yz = 'SGV' (and 'z'): the structure of U2V (R/vecchia_prediction.R:62-83) */
 SEXP gpvR_plan_build_posterior(SEXP xp, SEXP revNN, SEXP revCond)
 {
+    gpv_plan *pl = gpvR_get(xp);
+    int64_t Nlocs = 0;
+    int p = 0;
+    gpvR_dims(pl, &Nlocs, &p);
+    if (!Rf_isInteger(revNN) || !Rf_isMatrix(revNN)) Rf_error("revNNarray must be an integer matrix (storage.mode<-)");
+    if (!(Rf_isInteger(revCond) || Rf_isLogical(revCond)) || !Rf_isMatrix(revCond)) Rf_error("revCond must be a logical / integer matrix");
+    if ((int64_t)Rf_nrows(revNN) != Nlocs || Rf_ncols(revNN) != p || (int64_t)Rf_nrows(revCond) != Nlocs || Rf_ncols(revCond) != p)
+        Rf_error("revNNarray / revCond must be the %.0f x %d matrices the plan was created from", (double)Nlocs, p);
     const int *cond = Rf_isLogical(revCond) ? LOGICAL(revCond) : INTEGER(revCond);
-    gpvR_fail(gpv_plan_build_posterior(gpvR_get(xp), INTEGER(revNN), cond), "gpv_plan_build_posterior");
+    gpvR_fail(gpv_plan_build_posterior(pl, INTEGER(revNN), cond), "gpv_plan_build_posterior");
     int lev = 0;
-    (void)gpv_plan_posterior_levels(gpvR_get(xp), &lev);
+    (void)gpv_plan_posterior_levels(pl, &lev);
     return Rf_ScalarInteger(lev);
 }
 
@@ -113,7 +133,13 @@ SEXP gpvR_plan_eval(SEXP xp, SEXP covType, SEXP covparms, SEXP nuggets, SEXP fla
 {
     gpv_plan *pl = gpvR_get(xp);
     const int fl = Rf_asInteger(flags);
+    int64_t Nlocs = 0;
+    int p = 0;
+    gpvR_dims(pl, &Nlocs, &p);
     if (!Rf_isReal(covparms) || !Rf_isReal(nuggets)) Rf_error("covparms and nuggets must be double");
+    if (TYPEOF(covType) != STRSXP || LENGTH(covType) < 1) Rf_error("covType must be a character string");
+    if (XLENGTH(nuggets) != 1 && (int64_t)XLENGTH(nuggets) != Nlocs)
+        Rf_error("nuggets must have length 1 or %.0f (one per location of the plan)", (double)Nlocs);
     gpvR_fail(gpv_plan_eval(pl, CHAR(STRING_ELT(covType, 0)), REAL(covparms), LENGTH(covparms), REAL(nuggets),
                             (int64_t)XLENGTH(nuggets), fl, NULL, NULL), "gpv_plan_eval");
     SEXP sums = PROTECT(Rf_allocVector(REALSXP, GPV_NSUMS));
@@ -128,21 +154,30 @@ SEXP gpvR_plan_eval(SEXP xp, SEXP covType, SEXP covparms, SEXP nuggets, SEXP fla
 }
 
 /* mu.ord of R/vecchia_prediction.R:118-126 after an evaluation with GPV_WANT_MEAN (or GPV_WANT_MEAN_B for 'zy') */
-SEXP gpvR_plan_posterior_mean(SEXP xp, SEXP Nlocs)
+SEXP gpvR_plan_posterior_mean(SEXP xp, SEXP Nlocs_r)
 {
-    SEXP mu = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)Rf_asReal(Nlocs)));
-    gpvR_fail(gpv_plan_get_posterior_mean(gpvR_get(xp), REAL(mu)), "gpv_plan_get_posterior_mean");
+    gpv_plan *pl = gpvR_get(xp);
+    int64_t Nlocs = 0;
+    int p = 0;
+    gpvR_dims(pl, &Nlocs, &p);                       /* the library writes Nlocs doubles: the buffer is sized from the plan */
+    if ((int64_t)Rf_asReal(Nlocs_r) != Nlocs) Rf_error("the plan has %.0f locations, not %.0f", (double)Nlocs, Rf_asReal(Nlocs_r));
+    SEXP mu = PROTECT(Rf_allocVector(REALSXP, (R_xlen_t)Nlocs));
+    gpvR_fail(gpv_plan_get_posterior_mean(pl, REAL(mu)), "gpv_plan_get_posterior_mean");
     UNPROTECT(1);
     return mu;
 }
 
 /* Lentries (rows x p, column-major like U.entries$Lentries of R/createU.R:152-154) after an evaluation with GPV_WANT_U */
-SEXP gpvR_plan_Lentries(SEXP xp, SEXP p)
+SEXP gpvR_plan_Lentries(SEXP xp, SEXP p_r)
 {
-    int64_t a = 0, b = 0;
-    gpvR_fail(gpv_plan_rows(gpvR_get(xp), &a, &b), "gpv_plan_rows");
-    SEXP L = PROTECT(Rf_allocMatrix(REALSXP, (int)(b - a), Rf_asInteger(p)));
-    gpvR_fail(gpv_plan_get_Lentries(gpvR_get(xp), REAL(L)), "gpv_plan_get_Lentries");
+    gpv_plan *pl = gpvR_get(xp);
+    int64_t a = 0, b = 0, Nlocs = 0;
+    int p = 0;
+    gpvR_fail(gpv_plan_rows(pl, &a, &b), "gpv_plan_rows");
+    gpvR_dims(pl, &Nlocs, &p);                       /* rows x (m + 1) as the plan knows them */
+    if (Rf_asInteger(p_r) != p) Rf_error("the plan's rows have %d entries, not %d", p, Rf_asInteger(p_r));
+    SEXP L = PROTECT(Rf_allocMatrix(REALSXP, (int)(b - a), p));
+    gpvR_fail(gpv_plan_get_Lentries(pl, REAL(L)), "gpv_plan_get_Lentries");
     UNPROTECT(1);
     return L;
 }

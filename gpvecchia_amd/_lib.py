@@ -29,7 +29,7 @@ EXPORTS = [
     "gpv_U_NZentries", "gpv_U_NZentries_mat", "gpv_MaternFun", "gpv_EsqeFun",
     "gpv_plan_create", "gpv_plan_destroy", "gpv_plan_set_data", "gpv_plan_eval",
     "gpv_plan_get_sums", "gpv_plan_get_Lentries", "gpv_plan_get_Zentries",
-    "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_last_kernel_ms", "gpv_plan_set_kernel_timing",
+    "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_dims", "gpv_plan_last_kernel_ms", "gpv_plan_set_kernel_timing",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
     "gpv_plan_build_posterior", "gpv_plan_build_posterior_fill", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
     "gpv_plan_cache_clear", "gpv_plan_cache_stats", "gpv_plan_vl_begin", "gpv_plan_vl_step", "gpv_plan_vl_get",

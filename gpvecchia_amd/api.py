@@ -345,26 +345,26 @@ _R_LAYOUT_CACHE = []          # [(weakref(revNNarray), weakref(revCond), fingerp
 
 
 def _fingerprint(a):
-    """Cheap content fingerprint of an index array: shape, dtype and a CRC of a strided sample of at most ~64 K entries plus
-    the first and last rows (an in-place edit of the array between two calls almost surely changes it; the library's own
-    plan cache hashes the full content behind this)."""
-    import zlib
+    """Content fingerprint of an index array: shape, dtype and a hash of EVERY byte (xxh3-128 where the xxhash module is
+    there, ~10 GB/s: ~15 ms for the two arrays of n = 1e6, m = 30; zlib.crc32 otherwise).  An in-place edit of the array
+    between two calls changes it."""
     a = np.asarray(a)
-    flat = a.reshape(-1)
-    step = max(1, flat.size // 65536)
-    sample = np.ascontiguousarray(flat[::step])
-    crc = zlib.crc32(sample.tobytes())
-    if a.ndim == 2 and a.shape[0] > 0:
-        crc = zlib.crc32(np.ascontiguousarray(a[0]).tobytes(), crc)
-        crc = zlib.crc32(np.ascontiguousarray(a[-1]).tobytes(), crc)
-    return (a.shape, a.dtype.str, crc)
+    buf = a if a.flags.c_contiguous or a.flags.f_contiguous else np.ascontiguousarray(a)
+    mv = memoryview(buf.reshape(-1, order="A")).cast("B")
+    try:
+        import xxhash
+        dig = xxhash.xxh3_128_digest(mv)
+    except ImportError:
+        import zlib
+        dig = zlib.crc32(mv)
+    return (a.shape, a.dtype.str, a.strides, dig)
 
 
 def _r_layout_cached(revNNarray, revCond):
     """Column-major int32 copies (R's representation) of the two index arrays, kept for the arrays last seen: createU hands
     the SAME objects to U_NZentries at every optimiser step, and converting 2 x 31e6 entries costs ~60 ms, six times the
     library call.  A hit needs the same two objects (held by weak reference: the cache keeps no caller array alive) AND an
-    unchanged content fingerprint, so an array edited in place between two calls is converted again."""
+    unchanged hash of their whole content, so an array edited in place between two calls is converted again."""
     import weakref
     fp = (_fingerprint(revNNarray), _fingerprint(revCond))
     for wa, wb, f, nn_r, cd_r in _R_LAYOUT_CACHE:

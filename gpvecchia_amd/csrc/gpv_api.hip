@@ -327,6 +327,9 @@ struct gpv_plan {
     int32_t *d_colptr = nullptr, *d_crow = nullptr;
     int32_t *d_ccol = nullptr;
     int4 *d_colrec = nullptr, *d_rowrec = nullptr;
+    int4 *d_rr0 = nullptr;                           // first-round row-list records in schedule order (PostArgs::rr0)
+    std::vector<int64_t> lev_rr0;                    // [level] where its records start in d_rr0
+    int64_t top_rr0 = 0;                             // the dense top block's
     uint8_t *d_tp = nullptr;
     double2 *d_C = nullptr;
     int32_t *d_cboff = nullptr, *d_cdel = nullptr;   // block offsets in d_C (Morton order of the locations), and cboff - colptr
@@ -338,6 +341,7 @@ struct gpv_plan {
     double *d_avec = nullptr, *d_tvec = nullptr, *d_rdiag = nullptr, *d_post_part = nullptr,
            *d_zuser = nullptr;
     uint8_t *d_obs = nullptr;                        // [Nlocs] ordered layout: 1 = the location carries an observation; nullptr: all do
+    double *d_nug_masked = nullptr;                  // [Nlocs] the evaluation's nuggets with +Inf where d_obs == 0 (PostArgs::nuggets)
     std::vector<int32_t> levptr, levptr2;
     std::vector<int> lev_lpc;                        // lanes per column of every level's kernel (16 / 32 / 64), from its row lists
     // the posterior pass as a captured HIP graph (one per {denominator, denominator + mean}): ~140 (280) launches of a few
@@ -437,7 +441,7 @@ int gpv_plan_destroy(gpv_plan *pl)
                     pl->d_C, pl->d_cboff, pl->d_cdel, pl->d_ccol, pl->d_avec_base, pl->d_tvec, pl->d_rdiag, pl->d_post_part, pl->d_zuser,
                     pl->d_order2, pl->d_levptr2, pl->d_toppart, pl->d_u, pl->d_mu, pl->d_tp, pl->d_nug_post, pl->d_mt2[0], pl->d_mt2[1],
                     pl->d_vl_z, pl->d_vl_pm, pl->d_vl_y[0], pl->d_vl_y[1], pl->d_vl_out, pl->d_vl_flags, pl->d_ticket,
-                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec, pl->d_obs, pl->d_topinfo, pl->d_toprows};
+                    pl->d_vl_y0, pl->d_vl_part, pl->d_user_ord, pl->d_meanrec, pl->d_obs, pl->d_topinfo, pl->d_toprows, pl->d_rr0, pl->d_nug_masked};
     for (auto &g : pl->pgraph)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     for (void *q : ptrs)
@@ -745,6 +749,8 @@ int gpv_plan_set_observed(gpv_plan *pl, const int *obs_ord)
     if (!pl) return GPV_ERR_BAD_ARG;
     GPV_HIP(hipSetDevice(pl->device));
     if (pl->last_stream) GPV_HIP(hipStreamSynchronize(pl->last_stream));
+    for (auto &g : pl->pgraph)                        // the captured passes hold the address of the nuggets they read
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (!obs_ord) {                                   // back to "every location is observed"
         if (pl->d_obs) { GPV_HIP(hipFree(pl->d_obs)); pl->d_obs = nullptr; }
         return GPV_OK;
@@ -800,12 +806,17 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             GPV_HIP(hipMemcpyAsync(pl->d_nug_user, nuggets, sizeof(double) * (size_t)pl->Nlocs,
                                    hipMemcpyHostToDevice, st));
             GPV_HIP(launch_scatter(pl->d_nug_user, pl->d_newpos, pl->Nlocs, pl->d_nuggets, 1, 0, st));
-            // locations without an observation (prediction locations): the set kernel keeps the caller's value (0 in the
-            // reference's nuggets.all.ord, R/createU.R:75-77; such a location is only ever conditioned on as latent, where the
-            // nugget drops out), the posterior pass reads +Inf there: no 1/tau on the diagonal of W = U_y U_y^T, no z/tau in z2
-            if (pl->d_obs) GPV_HIP(launch_mask_unobserved(pl->d_nug_user, pl->d_obs, pl->Nlocs, st));
         } else {
             return GPV_ERR_BAD_ARG;
+        }
+        // locations without an observation (prediction locations): the set kernel keeps the caller's value (0 in the
+        // reference's nuggets.all.ord, R/createU.R:75-77; such a location is only ever conditioned on as latent, where the
+        // nugget drops out), the posterior pass reads +Inf there: no 1/tau on the diagonal of W = U_y U_y^T, no z/tau in z2.
+        // The masked values go to a buffer of their own that only the pass reads: Zentries, D_ord and the Vecchia-Laplace
+        // step keep seeing the caller's nuggets, and evaluations without a pass do not touch it.
+        if (pl->d_obs && !pl->nug_is_scalar && (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B))) {
+            if (!pl->d_nug_masked) GPV_HIP(hipMalloc((void **)&pl->d_nug_masked, sizeof(double) * (size_t)pl->Nlocs));
+            GPV_HIP(launch_mask_unobserved(pl->d_nug_user, pl->d_nug_masked, pl->d_obs, pl->Nlocs, st));
         }
         // with unobserved locations the posterior pass needs the per-location form (a constant cannot say "none here")
         if (pl->d_obs && (flags & (GPV_WANT_DENOM | GPV_WANT_MEAN_B)) && pl->nug_is_scalar) return GPV_ERR_BAD_ARG;
@@ -836,7 +847,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     a.ticket = pl->d_ticket;
     // the set kernel's totals are final (no posterior pass adds to them) and go to the plan's own host buffer: the kernel
     // appends the sequence number of this evaluation and gpv_plan_get_sums spins on it instead of waiting for the stream
-    static const bool no_seq = getenv("GPV_NO_SEQ_HANDOFF") != nullptr;
+    static const bool no_seq = dev_getenv("GPV_NO_SEQ_HANDOFF") != nullptr;
     unsigned long long *const seq_cells = reinterpret_cast<unsigned long long *>(pl->h_sums_dev + kNSums);
     // inside somebody's stream capture the sequence number would be frozen into the graph (every replay would publish the
     // same one, and gpv_plan_get_sums would accept the previous replay's totals without waiting): wait for the stream there
@@ -957,10 +968,11 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         pa.colptr = pl->d_colptr; pa.crow = pl->d_crow;
         pa.colrec = pl->d_colrec; pa.rowrec = pl->d_rowrec; pa.tp = pl->d_tp;
         pa.C = pl->d_C; pa.cboff = pl->d_cboff; pa.z = pl->d_zuser;
-        pa.nuggets = pl->nug_is_scalar ? nullptr : pl->d_nug_user;
+        pa.nuggets = pl->nug_is_scalar ? nullptr : (pl->d_obs ? pl->d_nug_masked : pl->d_nug_user);
         pa.nug_cell = pl->d_nug_post;
         pa.tvec = pl->d_tvec; pa.rdiag = pl->d_rdiag; pa.ld = pl->post_ld;
         pa.meanrec = pl->d_meanrec;
+        pa.rr0 = pl->d_rr0;
         const bool want_mean = (flags & GPV_WANT_MEAN) != 0;
         // cond.yz = 'zy' (R/vecchia_prediction.R:68-70,118-126): V.ord is the reversed latent block B of U itself, no
         // factorisation.  After createU's removal of the dummy latent variables (R/createU.R:166-171) no latent row has an
@@ -985,9 +997,10 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             }
             for (size_t lv = 0; e == hipSuccess && lv + 1 < pl->levptr.size(); ++lv)
                 e = launch_posterior_level(pa, pl->levptr[lv], pl->levptr[lv + 1] - pl->levptr[lv], lv == 0,
-                                           lv < pl->lev_lpc.size() ? pl->lev_lpc[lv] : 64, st);
+                                           lv < pl->lev_lpc.size() ? pl->lev_lpc[lv] : 64, pl->lev_rr0[lv], st);
             if (e == hipSuccess && pl->top_K > 0)
-                e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, pl->d_topinfo, pl->d_toprows, st);
+                e = launch_posterior_top(pa, (int)(pl->Nlocs - pl->top_K), pl->top_K, pl->d_toppart, pl->d_topinfo, pl->d_toprows,
+                                         pl->top_rr0, st);
             if (e == hipSuccess)
                 e = launch_sum_pair(pl->d_rdiag, pl->d_tvec, pl->Nlocs, pl->d_post_part, pl->d_sums, mirror, st);
             if (want_mean) {
@@ -1002,7 +1015,7 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
             }
             return e;
         };
-        static const bool post_skip = getenv("GPV_POST_SKIP") != nullptr;   // developer aid (timing only, results are WRONG): the set
+        static const bool post_skip = dev_getenv("GPV_POST_SKIP") != nullptr;   // developer aid (timing only, results are WRONG): the set
         if (post_skip) { pl->last_stream = st; pl->evaluated = true; return GPV_OK; }   // kernel of mode S without its pass
         gpv_plan::PostGraph &g = pl->pgraph[(want_mean ? 1 : 0) + (pl->nug_is_scalar ? 0 : 2) + (mean_b ? 4 : 0)];
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -1156,6 +1169,12 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     // lists, row lists and a level schedule; parameter independent, built once.
     if (fill_ratio) *fill_ratio = 1.0;
     if (!pl || !revNN || !revCond) return GPV_ERR_BAD_ARG;
+    // a rebuild that fails half way must not leave the old schedule's graphs and flag over new tables: the plan has no
+    // posterior structure from here until the last line of this function
+    pl->have_post = false;
+    if (pl->last_stream) { GPV_HIP(hipSetDevice(pl->device)); GPV_HIP(hipStreamSynchronize(pl->last_stream)); }
+    for (auto &g : pl->pgraph)
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (pl->row_begin != 0 || pl->row_end != pl->Nlocs) return GPV_ERR_BAD_ARG;   // not shardable
     if (pl->p > 64) return GPV_ERR_UNSUPPORTED_M;      // the level kernels own one lane per row of a column (<= 64)
     if (pl->Nlocs >= (int64_t)1 << 31) return GPV_ERR_BAD_ARG;
@@ -1372,7 +1391,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         for (int64_t k = 0; k < n; ++k) inv[(size_t)(have_pos ? pl->h_newpos[(size_t)k] : (int32_t)k)] = (int32_t)k;
         // blocks start on 64-byte boundaries (4 entries): --mode S 433.5-433.8 -> 435.0-435.4 evaluations/s at n = 1e6, m = 30
         // (128 bytes: the same), for <= 5 % more memory.  GPV_POST_ALIGN (developer A/B): entries per boundary
-        static const int al = getenv("GPV_POST_ALIGN") ? std::max(1, atoi(getenv("GPV_POST_ALIGN"))) : 4;
+        static const int al = dev_getenv("GPV_POST_ALIGN") ? std::max(1, atoi(dev_getenv("GPV_POST_ALIGN"))) : 4;
         int64_t off = 0;
         for (int64_t r = 0; r < n; ++r) {
             const int32_t k = inv[(size_t)r];
@@ -1398,7 +1417,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     // lanes per column of a level: by the mean length of its row lists (the column itself included): rounds of 4 / 8 / 16
     // columns.  GPV_POST_LPC=64 (or 16, 32) in the environment forces one form (developer A/B).
     {
-        const char *force = getenv("GPV_POST_LPC");
+        const char *force = dev_getenv("GPV_POST_LPC");
         pl->lev_lpc.assign((size_t)(maxlev + 1), 64);
         for (int32_t l = 0; l <= maxlev; ++l) {
             const int32_t b0 = pl->levptr[(size_t)l], e0 = pl->levptr[(size_t)l + 1];
@@ -1406,12 +1425,12 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
             double tot = 0.0;
             for (int32_t i = b0; i < e0; ++i) tot += rowptr[(size_t)order[(size_t)i] + 1] - rowptr[(size_t)order[(size_t)i]];
             const double mean = tot / (e0 - b0);
-            static const double t16 = getenv("GPV_POST_T16") ? atof(getenv("GPV_POST_T16")) : 4.5;
-            static const double t32 = getenv("GPV_POST_T32") ? atof(getenv("GPV_POST_T32")) : 10.0;
+            static const double t16 = dev_getenv("GPV_POST_T16") ? atof(dev_getenv("GPV_POST_T16")) : 4.5;
+            static const double t32 = dev_getenv("GPV_POST_T32") ? atof(dev_getenv("GPV_POST_T32")) : 10.0;
             int lpc = mean <= t16 ? 16 : (mean <= t32 ? 32 : 64);
             if (force) lpc = atoi(force);
             pl->lev_lpc[(size_t)l] = (lpc == 16 || lpc == 32) ? lpc : 64;
-            static const bool dbg = getenv("GPV_POST_DEBUG") != nullptr;       // developer: the schedule's shape, level by level
+            static const bool dbg = dev_getenv("GPV_POST_DEBUG") != nullptr;       // developer: the schedule's shape, level by level
             if (dbg) std::fprintf(stderr, "[gpv post] level %d: %d columns, mean row list %.1f, lanes/column %d\n", (int)l,
                                   (int)(e0 - b0), mean, pl->lev_lpc[(size_t)l]);
         }
@@ -1431,6 +1450,33 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
             rowrec[q] = make_int4(cboff[(size_t)c], tptr[q], e | ((e + 1 < cn ? e + 1 : 0) << 8), (int)in_top[(size_t)c]);   // .w: column c is in the top block
             ccol[(size_t)(b0 + e)] = (int32_t)c;
         }
+    }
+
+    // PostArgs::rr0: the first round of every scheduled column's row list in schedule order, at the stride of its level's kernel
+    std::vector<int4> rr0;
+    {
+        pl->lev_rr0.assign((size_t)(maxlev + 1), 0);
+        int64_t tot = 0;
+        std::vector<int> stride((size_t)(maxlev + 1), 0);
+        for (int32_t l = 0; l <= maxlev; ++l) {
+            const int cntl = pl->levptr[(size_t)l + 1] - pl->levptr[(size_t)l];
+            stride[(size_t)l] = posterior_level_form(cntl, l == 0, pl->lev_lpc[(size_t)l], pl->post_ld).rr0_stride;
+            pl->lev_rr0[(size_t)l] = tot;
+            tot += (int64_t)cntl * stride[(size_t)l];
+        }
+        pl->top_rr0 = tot;
+        tot += K * kTopRr0Stride;
+        rr0.resize((size_t)tot + 1);
+        auto fill_col = [&](int4 *dst, int32_t k, int st) {
+            const int32_t qb = rowptr[(size_t)k], qe = rowptr[(size_t)k + 1];
+            for (int s2 = 0; s2 < st; ++s2) dst[s2] = rowrec[(size_t)(qb + s2 < qe ? qb + s2 : qb)];
+        };
+        for (int32_t l = 0; l <= maxlev; ++l)
+            for (int32_t i = pl->levptr[(size_t)l]; i < pl->levptr[(size_t)l + 1] && stride[(size_t)l] > 0; ++i)
+                fill_col(rr0.data() + pl->lev_rr0[(size_t)l] + (int64_t)(i - pl->levptr[(size_t)l]) * stride[(size_t)l],
+                         order[(size_t)i], stride[(size_t)l]);
+        for (int64_t j = 0; j < K; ++j)
+            fill_col(rr0.data() + pl->top_rr0 + j * kTopRr0Stride, topcols[(size_t)j], kTopRr0Stride);
     }
 
     // the top block's own tables: where each of its columns lives, and the index inside the block of each entry's row
@@ -1481,7 +1527,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         std::vector<int32_t> rid((size_t)rows);
         GPV_HIP(hipMemcpy(cdh.data(), pl->d_cond, cdh.size(), hipMemcpyDeviceToHost));
         GPV_HIP(hipMemcpy(rid.data(), pl->d_rowid, rid.size() * 4, hipMemcpyDeviceToHost));
-        const bool fuse = !with_fill && !pl->generic && getenv("GPV_POST_NO_FUSE") == nullptr;
+        const bool fuse = !with_fill && !pl->generic && dev_getenv("GPV_POST_NO_FUSE") == nullptr;
         const int32_t *cp_ = colptr.data();
         const uint8_t *cs_ = cslot.data();
         uint8_t *cd_ = cdh.data();
@@ -1515,6 +1561,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     if ((rc = up((void **)&pl->d_cslot, cslot.data(), nnz)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_colrec, colrec.data(), colrec.size() * sizeof(int4))) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_rowrec, rowrec.data(), rowrec.size() * sizeof(int4))) != GPV_OK) return rc;
+    if ((rc = up((void **)&pl->d_rr0, rr0.data(), rr0.size() * sizeof(int4))) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_tp, tp.data(), tp.size())) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_ccol, ccol.data(), nnz * 4)) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_cboff, cboff.data(), cboff.size() * 4)) != GPV_OK) return rc;
@@ -1537,7 +1584,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     if ((rc = up((void **)&pl->d_topinfo, topinfo.data(), topinfo.size() * sizeof(int2))) != GPV_OK) return rc;
     if ((rc = up((void **)&pl->d_toprows, toprows.data(), toprows.size())) != GPV_OK) return rc;
     pl->mean_head_levels = 0;
-    static const bool no_head = getenv("GPV_NO_MEAN_HEAD") != nullptr;
+    static const bool no_head = dev_getenv("GPV_NO_MEAN_HEAD") != nullptr;
     while (!no_head && (size_t)pl->mean_head_levels + 1 < pl->levptr2.size() &&
            pl->levptr2[(size_t)pl->mean_head_levels + 1] - pl->levptr2[(size_t)pl->mean_head_levels] <= kMeanHeadMax)
         ++pl->mean_head_levels;
@@ -1879,7 +1926,7 @@ int gpv_plan_get_Lentries(gpv_plan *pl, double *Lentries)
     if (!pl->d_tmp) GPV_HIP(hipMalloc((void **)&pl->d_tmp, bytes));
     hipStream_t st = pl->last_stream;
     GPV_HIP(launch_rows_to_colmajor(pl->d_L, pl->P, pl->rows, pl->p, pl->d_tmp, st));
-    static const bool no_stage = getenv("GPV_NO_D2H_STAGING") != nullptr;
+    static const bool no_stage = dev_getenv("GPV_NO_D2H_STAGING") != nullptr;
     constexpr size_t kChunk = (size_t)32 << 20;
     if (no_stage || bytes < 2 * kChunk) {
         GPV_HIP(hipMemcpyAsync(Lentries, pl->d_tmp, bytes, hipMemcpyDeviceToHost, st));
@@ -1946,6 +1993,15 @@ int gpv_plan_rows(gpv_plan *pl, int64_t *row_begin, int64_t *row_end)
     if (!pl || !row_begin || !row_end) return GPV_ERR_BAD_ARG;
     *row_begin = pl->row_begin;
     *row_end = pl->row_end;
+    return GPV_OK;
+}
+
+int gpv_plan_dims(gpv_plan *pl, int64_t *Nlocs, int *dim, int *ncolNN)
+{
+    if (!pl) return GPV_ERR_BAD_ARG;
+    if (Nlocs) *Nlocs = pl->Nlocs;
+    if (dim) *dim = pl->dim;
+    if (ncolNN) *ncolNN = pl->p;
     return GPV_OK;
 }
 

@@ -174,16 +174,17 @@ hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s)
     return hipGetLastError();
 }
 
-__global__ void gpv_mask_unobserved_kernel(double *x, const uint8_t *keep, int64_t n)
+// dst = src with +Inf where keep == 0 (a COPY: the caller's nuggets stay what they were for Zentries, D_ord, the next step)
+__global__ void gpv_mask_unobserved_kernel(const double *src, double *dst, const uint8_t *keep, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        if (!keep[i]) x[i] = __builtin_huge_val();
+        dst[i] = keep[i] ? src[i] : __builtin_huge_val();
 }
-hipError_t launch_mask_unobserved(double *x, const uint8_t *keep, int64_t n, hipStream_t s)
+hipError_t launch_mask_unobserved(const double *src, double *dst, const uint8_t *keep, int64_t n, hipStream_t s)
 {
     if (n <= 0) return hipSuccess;
     int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gpv_mask_unobserved_kernel, dim3(grid), dim3(256), 0, s, x, keep, n);
+    hipLaunchKernelGGL(gpv_mask_unobserved_kernel, dim3(grid), dim3(256), 0, s, src, dst, keep, n);
     return hipGetLastError();
 }
 

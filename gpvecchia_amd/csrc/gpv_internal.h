@@ -3,9 +3,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "gpv_bessel.hpp"
 
 namespace gpv {
+
+// Environment switches (the full table: DESIGN.md §8).  The shipped library reads only the documented ones that choose
+// between exact routes (getenv).  The tuning knobs of rejected or alternative forms, some of which give WRONG results on
+// purpose (GPV_POST_SKIP), go through dev_getenv and exist only in developer builds:
+//     python -m gpvecchia_amd.build --tag _dev --flags=-DGPV_DEVELOPER
+#ifdef GPV_DEVELOPER
+inline const char *dev_getenv(const char *name) { return getenv(name); }
+#else
+inline const char *dev_getenv(const char *) { return nullptr; }
+#endif
 
 // covariance family evaluated inside the conditioning-set kernel
 //   matern branches: src/Matern.cpp:32-42 (nu .5), :43-57 (1.5), :58-71 (2.5); esqe: src/Esqe.cpp:17-39
@@ -84,7 +95,7 @@ hipError_t launch_fill(double *dst, double value, int64_t n, hipStream_t s);
 // dst[pos[i] * stride + offset] = src[i]
 hipError_t launch_scatter(const double *src, const int32_t *pos, int64_t n, double *dst, int stride, int offset, hipStream_t s);
 // x[i] = +Inf where keep[i] == 0 (per-location nuggets as the posterior pass reads them: no observation at a prediction location)
-hipError_t launch_mask_unobserved(double *x, const uint8_t *keep, int64_t n, hipStream_t s);
+hipError_t launch_mask_unobserved(const double *src, double *dst, const uint8_t *keep, int64_t n, hipStream_t s);
 hipError_t launch_zentries(const double *nuggets_obsord, int64_t n, double *Z, hipStream_t s);
 hipError_t launch_rows_to_colmajor(const double *src, int ld, int64_t rows, int cols, double *dst, hipStream_t s);
 hipError_t launch_covfun(const double *dist, int64_t n, int cov, double sig0, double sA, double cA, double sB,
@@ -121,7 +132,16 @@ struct PostArgs {
     double *rdiag;           // [n] R_kk (the logarithms are taken by the reduction that sums them)
     int ld;                  // row length of Lentries (bounds the entries per column)
     const int4 *meanrec;     // [n] mean sweep: {k, cboff[k], entries, colptr[k]} in the order of its schedule, or nullptr
+    // the FIRST round of every column's row list once more, in the order of the schedule and at a fixed stride per level
+    // (posterior_level_form): the wave that takes position j of a level requests these records together with its column
+    // record, by position alone, so that a column is two dependent trips to memory (record -> blocks), not three
+    // (column record -> row-list records -> blocks).  Slots past the end of a short list repeat the list's first record.
+    const int4 *rr0;
 };
+// which kernel runs a level of `count` columns, and how many first-round records per column it reads from PostArgs::rr0
+enum PostKind { kPostLeaf = 0, kPostGroup16, kPostGroup32, kPostWave1, kPostWave8, kPostWave16 };
+struct PostForm { PostKind kind; int rr0_stride; };
+PostForm posterior_level_form(int count, bool leaves, int lanes_per_column, int ld);
 // C <- (Lentries, a): ccol/cslot give column and Lentries slot of every compact entry
 // cdel[c] = cboff[c] - colptr[c]
 // (both = true: C <- (B, B), for the mean of cond.yz = 'zy' where the factor IS the latent block)
@@ -130,7 +150,9 @@ hipError_t launch_posterior_compact(const double *L, int ld, const double *avec,
                                     hipStream_t s);
 // columns [first, first+count) of the level-ordered records; leaves = the level's row lists hold the column only (level 0)
 // lanes_per_column: 64 (one wavefront per column) or 16 / 32 for levels whose row lists are short (several columns per wavefront)
-hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, int lanes_per_column, hipStream_t s);
+// rr0_off: where the level's first-round records start in PostArgs::rr0
+hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, int lanes_per_column, int64_t rr0_off,
+                                  hipStream_t s);
 // posterior mean (R/vecchia_prediction.R:118-126): solve R^T u = t column by column in ASCENDING dependency
 // order (order2), mu_ord = -u
 hipError_t launch_mean_level(const PostArgs &a, const int32_t *order2, double *u, int first, int count, hipStream_t s);

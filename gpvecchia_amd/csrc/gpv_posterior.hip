@@ -93,8 +93,8 @@ __device__ __forceinline__ double post_rcp(const double x)
 // per column (~35 of the ~260 VALU instructions a column cost in the wide levels, which are VALU bound).  Needs
 // cnt + 2 <= 64 row-sum lanes: plans with m + 1 <= 62; longer rows keep the butterflies.
 template <int WPC, int MODE = 0, bool ZST = false>
-__device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, const int4 c1, double *T, const int wib,
-                                            const int lane, double *tpart = nullptr)
+__device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, const int4 c1, const int4 rrf, double *T,
+                                            const int wib, const int lane, double *tpart = nullptr)
 {
     const int k = c0.x;
     const int cnt = c0.z;                            // latent entries of column k, ascending rows, self (= k) last
@@ -114,15 +114,20 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     const int srow = two ? (lane & 31) : lane, shalf = two ? (lane >> 5) : 0;
 
     double acc = 0.0, z2 = 0.0, s = 0.0;
+    bool first_round = true;
     for (int base = qb + kRC * ((WPC == 1) ? 0 : wib); base < qe; base += kRC * WPC) {
         const int q = base + col;
         // One trip for everything the round reads behind the row-list record: the (a_c, t_c) head, the (B_kc, R_kc) pair, and
         // the first EC match bytes and (B, R) pairs of each lane.  No branches around the loads (an idle lane reads the
         // round's first record, an entry past the end reads entry 0, both masked afterwards): with per-lane branches the
         // compiler serialises them into two dependent trips.
+        // The wave's FIRST round has its records already: rrf came with the column record (PostArgs::rr0), so its gathers
+        // leave together with the loads of the column's own block.
         constexpr int EC = GPV_POST_EC;
         const bool act = q < qe;
-        const int4 rr = nt_load(&A.rowrec[act ? q : base]);
+        int4 rr = rrf;
+        if (!first_round) rr = nt_load(&A.rowrec[act ? q : base]);
+        first_round = false;
         const double2 *Cc = A.C + rr.x;
         const int ne = act ? (rr.z >> 8) : 0;   // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
         const int tb = rr.y;
@@ -243,7 +248,8 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
 
 template <int WPC, int MODE = 0, bool ZST = false>
 __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level_kernel(const PostArgs A, int first, int count,
-                                                                                        double *toppart, int top_base)
+                                                                                        double *toppart, int top_base,
+                                                                                        const int4 *rr0lev)
 {
     extern __shared__ double tile_all[];
     const int lane = threadIdx.x & 63;
@@ -255,7 +261,9 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     // set kernel's index stream and location records out of the Infinity Cache between evaluations
     const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
     const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
-    post_column<WPC, MODE, ZST>(A, c0, c1, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
+    // the first round's row-list records by position alone (kRC * WPC per column, this wave's 16 of them)
+    const int4 rrf = nt_load(&rr0lev[(size_t)w * (kRC * WPC) + (WPC == 1 ? 0 : wib * kRC) + (lane >> 2)]);
+    post_column<WPC, MODE, ZST>(A, c0, c1, rrf, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
 }
 
 // ---- several columns per wavefront ----------------------------------------------------------------------------------
@@ -267,7 +275,8 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
 // a fixed order of every sum => bitwise reproducible; the order differs from the 64-lane kernel's (results equal to
 // rounding).  The two scalar sums ride in the tile like in the ZST form above (needs m + 1 <= 62).
 template <int LPC>
-__global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const PostArgs A, int first, int count)
+__global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const PostArgs A, int first, int count,
+                                                                        const int4 *rr0lev)
 {
     static_assert(LPC == 16 || LPC == 32, "lanes per column");
     constexpr int G = 64 / LPC, RCG = LPC / kSub, TSG = RCG + 1, NJ = 64 / LPC;   // groups, columns per round, tile stride, rows per lane
@@ -281,6 +290,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
     double *T = tile_all + ((size_t)wib * G + g) * (A.ld + 2) * TSG;
     const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0))]);
     const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0)) + 1]);
+    const int4 rrf = nt_load(&rr0lev[(size_t)(live ? wcol : 0) * RCG + col]);   // first round: with the column record
     const int k = c0.x, cnt = c0.z, nrow = cnt + 2;
     const int qb = c0.w, qe = live ? c1.x : c0.w;                               // (a group without a column runs no round)
     double2 *Ck = A.C + c0.y;
@@ -293,10 +303,13 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
     double acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = 0.0;
+    bool first_round = true;
     for (int base = qb; __builtin_amdgcn_ballot_w64(base < qe) != 0; base += RCG) {
         const int q = base + col;
         const bool act = q < qe;
-        const int4 rr = nt_load(&A.rowrec[act ? q : qb]);
+        int4 rr = rrf;
+        if (!first_round) rr = nt_load(&A.rowrec[act ? q : qb]);
+        first_round = false;
         const double2 *Cc = A.C + rr.x;
         const int ne = act ? (rr.z >> 8) : 0;
         const int tb = rr.y;
@@ -884,14 +897,16 @@ __global__ void __launch_bounds__(64 * kTop2Waves) gpv_posterior_top2_kernel(con
 // (GPV_POST_ZST=0 in the environment keeps the cross-lane butterflies: same-box A/B of the tile-row sums)
 static bool zst_enabled(int ld)
 {
-    static const bool off = getenv("GPV_POST_ZST") != nullptr && atoi(getenv("GPV_POST_ZST")) == 0;
+    static const bool off = dev_getenv("GPV_POST_ZST") != nullptr && atoi(dev_getenv("GPV_POST_ZST")) == 0;
     return !off && ld + 2 <= 64;
 }
 
 // the top block: positions [first, first + K) of the column records hold the columns 0 .. K-1; tpart: [K][66] scratch
 hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, const int2 *topinfo, const uint8_t *toprows,
-                                hipStream_t s)
+                                int64_t rr0_off, hipStream_t s)
 {
+    static_assert(kTopRr0Stride == 16 * kRC, "the top block's columns are prepared by 16 waves each");
+    const int4 *rr0 = a.rr0 + rr0_off;
     if (K <= 0) return hipSuccess;
     if (K > kTopMax) return hipErrorInvalidValue;
     const size_t smem = (size_t)16 * (a.ld + 2) * kTS * sizeof(double);
@@ -902,15 +917,17 @@ hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpa
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done.load(std::memory_order_relaxed) & bit)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 1, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+            if (e1 != hipSuccess) return e1;
+            if (e2 != hipSuccess) return e2;
             done.fetch_or(bit, std::memory_order_relaxed);
         }
     }
-    if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, true>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
-    else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, false>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first);
+    if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, true>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first, rr0);
+    else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 1, false>), dim3(K), dim3(1024), smem, s, a, first, K, tpart, first, rr0);
     if (K <= kTop) {
         hipLaunchKernelGGL(gpv_posterior_top_kernel, dim3(1), dim3(64 * kTopWaves), 0, s, a, (const double *)tpart, K, topinfo, toprows);
         return hipGetLastError();
@@ -921,8 +938,9 @@ hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpa
         (void)hipGetDevice(&dev);
         const unsigned long long bit = 1ull << (dev & 63);
         if (!(done2.load(std::memory_order_relaxed) & bit)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_top2_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTop2Smem);
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_top2_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTop2Smem);
+            if (e1 != hipSuccess) return e1;
             done2.fetch_or(bit, std::memory_order_relaxed);
         }
     }
@@ -931,26 +949,41 @@ hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpa
     return hipGetLastError();
 }
 
-hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, int lanes_per_column, hipStream_t s)
+// The kernel that runs a level, and how many first-round records per column it reads from PostArgs::rr0.  One function for the
+// plan builder (which lays the records out) and the launcher.
+PostForm posterior_level_form(int count, bool leaves, int lanes_per_column, int ld)
+{
+    if (leaves) return PostForm{kPostLeaf, 0};
+    if (lanes_per_column < 64 && zst_enabled(ld) && count > GPV_POST_WIDE)       // short row lists: 4 or 2 columns per wavefront
+        return lanes_per_column == 16 ? PostForm{kPostGroup16, 16 / kSub} : PostForm{kPostGroup32, 32 / kSub};
+    static const int wide16 = dev_getenv("GPV_POST_WIDE16") ? atoi(dev_getenv("GPV_POST_WIDE16")) : GPV_POST_WIDE16;
+    static const int wide8 = dev_getenv("GPV_POST_WIDE") ? atoi(dev_getenv("GPV_POST_WIDE")) : GPV_POST_WIDE;
+    if (count <= wide16) return PostForm{kPostWave16, 16 * kRC};                 // narrowest levels: 16 waves per column
+    if (count <= wide8) return PostForm{kPostWave8, 8 * kRC};                    // narrow level: 8 waves per column
+    return PostForm{kPostWave1, kRC};
+}
+
+hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool leaves, int lanes_per_column, int64_t rr0_off,
+                                  hipStream_t s)
 {
     if (count <= 0) return hipSuccess;
     double *const np = nullptr;
-    if (leaves) {
+    const PostForm form = posterior_level_form(count, leaves, lanes_per_column, a.ld);
+    const int4 *rr0 = a.rr0 + rr0_off;
+    if (form.kind == kPostLeaf) {
         hipLaunchKernelGGL(gpv_posterior_leaf_kernel, dim3((count + 15) / 16), dim3(256), 0, s, a, first, count);
         return hipGetLastError();
     }
-    if (lanes_per_column < 64 && zst_enabled(a.ld) && count > GPV_POST_WIDE) {   // short row lists: 4 or 2 columns per wavefront
+    if (form.kind == kPostGroup16 || form.kind == kPostGroup32) {
         const int wpb = 4, G = 64 / lanes_per_column;
         const size_t smem = (size_t)wpb * G * (a.ld + 2) * (lanes_per_column / kSub + 1) * sizeof(double);
         const int grid = (count + wpb * G - 1) / (wpb * G);
-        if (lanes_per_column == 16) hipLaunchKernelGGL((gpv_posterior_level_group_kernel<16>), dim3(grid), dim3(wpb * 64), smem, s, a, first, count);
-        else hipLaunchKernelGGL((gpv_posterior_level_group_kernel<32>), dim3(grid), dim3(wpb * 64), smem, s, a, first, count);
+        if (lanes_per_column == 16) hipLaunchKernelGGL((gpv_posterior_level_group_kernel<16>), dim3(grid), dim3(wpb * 64), smem, s, a, first, count, rr0);
+        else hipLaunchKernelGGL((gpv_posterior_level_group_kernel<32>), dim3(grid), dim3(wpb * 64), smem, s, a, first, count, rr0);
         return hipGetLastError();
     }
     const bool zst = zst_enabled(a.ld);
-    static const int wide16 = getenv("GPV_POST_WIDE16") ? atoi(getenv("GPV_POST_WIDE16")) : GPV_POST_WIDE16;
-    static const int wide8 = getenv("GPV_POST_WIDE") ? atoi(getenv("GPV_POST_WIDE")) : GPV_POST_WIDE;
-    if (count <= wide16) {                           // narrowest levels: 16 waves per column (all rounds in flight)
+    if (form.kind == kPostWave16) {
         const size_t smem = (size_t)16 * (a.ld + 2) * kTS * sizeof(double);
         if (smem > 64 * 1024) {                               // > 64 KiB of dynamic LDS needs the opt-in, once per device
             static std::atomic<unsigned long long> done{0ull};
@@ -958,27 +991,29 @@ hipError_t launch_posterior_level(const PostArgs &a, int first, int count, bool 
             (void)hipGetDevice(&dev);
             const unsigned long long bit = 1ull << (dev & 63);
             if (!(done.load(std::memory_order_relaxed) & bit)) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0, false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0, true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+                hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0, false>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_posterior_level_kernel<16, 0, true>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+                if (e1 != hipSuccess) return e1;
+                if (e2 != hipSuccess) return e2;
                 done.fetch_or(bit, std::memory_order_relaxed);
             }
         }
-        if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, true>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
-        else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, false>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0);
+        if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, true>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0, rr0);
+        else hipLaunchKernelGGL((gpv_posterior_level_kernel<16, 0, false>), dim3(count), dim3(1024), smem, s, a, first, count, np, 0, rr0);
         return hipGetLastError();
     }
-    if (count <= wide8) {                                     // narrow level: the chip is not full anyway, 8 waves per column
+    if (form.kind == kPostWave8) {
         const size_t smem = (size_t)8 * (a.ld + 2) * kTS * sizeof(double);
-        if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, true>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
-        else hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, false>), dim3(count), dim3(512), smem, s, a, first, count, np, 0);
+        if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, true>), dim3(count), dim3(512), smem, s, a, first, count, np, 0, rr0);
+        else hipLaunchKernelGGL((gpv_posterior_level_kernel<8, 0, false>), dim3(count), dim3(512), smem, s, a, first, count, np, 0, rr0);
         return hipGetLastError();
     }
     const int wpb = 4;
     const size_t smem = (size_t)wpb * (a.ld + 2) * kTS * sizeof(double);
-    if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0, true>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0);
-    else hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0, false>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0);
+    if (zst) hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0, true>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0, rr0);
+    else hipLaunchKernelGGL((gpv_posterior_level_kernel<1, 0, false>), dim3((count + wpb - 1) / wpb), dim3(wpb * 64), smem, s, a, first, count, np, 0, rr0);
     return hipGetLastError();
 }
 
@@ -1153,8 +1188,9 @@ hipError_t launch_mean_top(const PostArgs &a, double *u, int K, const int2 *topi
     (void)hipGetDevice(&dev);
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(done.load(std::memory_order_relaxed) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_mean_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)kMeanTopSmem);
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&gpv_mean_top_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)kMeanTopSmem);
+        if (e1 != hipSuccess) return e1;
         done.fetch_or(bit, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(gpv_mean_top_kernel, dim3(1), dim3(1024), kMeanTopSmem, s, a, u, K, topinfo, toprows);

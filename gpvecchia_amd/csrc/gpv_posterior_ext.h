@@ -16,8 +16,10 @@ hipError_t launch_mean_head(const PostArgs &a, const int32_t *order2, double *u,
 // the row-list pairs whose column is in T; tpart: [K][66]; topinfo[j] = {column, its block's offset in C}; toprows[j][e] = the
 // index INSIDE the block of entry e's row (0xFF: no such entry).
 constexpr int kTopBlock = 64, kTopMax = 2 * kTopBlock;
+// rr0_off: the block's first-round records (stride kTopRr0Stride per column) in PostArgs::rr0
+constexpr int kTopRr0Stride = 256;
 hipError_t launch_posterior_top(const PostArgs &a, int first, int K, double *tpart, const int2 *topinfo, const uint8_t *toprows,
-                                hipStream_t s);
+                                int64_t rr0_off, hipStream_t s);
 // Mean sweep, the columns of T: the plan's ascending schedule (order2 / levptr2 / meanrec) holds the OTHER columns only
 hipError_t launch_mean_top(const PostArgs &a, double *u, int K, const int2 *topinfo, const uint8_t *toprows, hipStream_t s);
 }  // namespace gpv

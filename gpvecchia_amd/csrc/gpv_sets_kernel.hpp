@@ -1535,9 +1535,9 @@ hipError_t launch_sets_PDC(const SetArgs &a_in, int cus, int *grid_out, hipStrea
     //     and 2 : 1; 125 000 rows (one rank of eight): 172 -> 159 us; m = 20, n = 1e5: 96.8 -> 92.1; general nu, n = 1e6:
     //     1721 -> 1666.
     //   * otherwise (single-wave workgroups, m + 1 > 48): one workgroup per slot below 48 tasks per slot, four above.
-    static const int mult_env = getenv("GPV_GRID_MULT") ? atoi(getenv("GPV_GRID_MULT")) : 0;
-    static const bool no_uneven = getenv("GPV_NO_UNEVEN") != nullptr;
-    static const char *shares_env = getenv("GPV_SHARES");            // developer aid: "3,2"
+    static const int mult_env = dev_getenv("GPV_GRID_MULT") ? atoi(dev_getenv("GPV_GRID_MULT")) : 0;
+    static const bool no_uneven = dev_getenv("GPV_NO_UNEVEN") != nullptr;
+    static const char *shares_env = dev_getenv("GPV_SHARES");            // developer aid: "3,2"
     const int64_t slots = (int64_t)cus * blocks_per_cu<P, D, COV>() * W;
     const bool paired = !no_uneven && W == 4 && blocks_per_cu<P, D, COV>() == 2 && (cus % 8) == 0 && tasks >= 3 * slots;
     const int mult = mult_env > 0 ? mult_env : (paired ? 1 : (tasks < 48 * slots ? 1 : 4));

@@ -249,6 +249,10 @@ int gpv_plan_get_Zentries(gpv_plan *plan, double *Zentries /* 2*(row_end-row_beg
 /* device views for callers that keep U on the GPU: row-major [rows][ld] doubles */
 int gpv_plan_Lentries_device(gpv_plan *plan, double **d_ptr, int64_t *ld);
 int gpv_plan_rows(gpv_plan *plan, int64_t *row_begin, int64_t *row_end);
+/* the shape the plan was created with: Nlocs (rows of locsord = length of z_ord, of a nugget vector, of the posterior mean),
+ * dim, ncolNN (= m + 1).  A binding sizes and checks its buffers from these, never from caller-supplied lengths
+ * (bindings/R/src/gpvR_plan.c).  Any pointer may be NULL. */
+int gpv_plan_dims(gpv_plan *plan, int64_t *Nlocs, int *dim, int *ncolNN);
 /* milliseconds the last eval's conditioning-set kernel took on the device (hipEvent pair around that launch) */
 int gpv_plan_last_kernel_ms(gpv_plan *plan, double *ms);
 /* on = 0: evaluations no longer record that event pair (two queue packets per evaluation; they matter only when an

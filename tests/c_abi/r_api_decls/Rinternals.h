@@ -12,6 +12,7 @@ typedef int Rboolean;
 #define TRUE 1
 #define FALSE 0
 #define REALSXP 14
+#define STRSXP 16
 #define EXTPTRSXP 22
 extern SEXP R_NilValue;
 extern double R_NaReal;

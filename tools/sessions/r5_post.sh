@@ -1,0 +1,23 @@
+#!/bin/bash
+# round 5: the posterior pass with first-round records (PostArgs::rr0): tests, same-box A/B against the tagged library
+# of the previous commit (gpvecchia_amd/libgpvecchia_hip_base.so), per-level kernel times of both
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5b; mkdir -p $O
+timeout 2400 python -m pytest tests/test_gpu_posterior_oracle.py tests/test_gpu_bench_nranks.py tests/test_gpu_fuzz.py tests/test_gpu_prediction.py -m gpu -x -q --durations=8 > $O/tests1.txt 2>&1
+tail -14 $O/tests1.txt
+timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -m gpu -x -q -k "posterior or sgv or SGV or top or latent or denom or C5 or vl or laplace or mean" > $O/tests2.txt 2>&1
+tail -5 $O/tests2.txt
+for rep in 1 2; do
+  for t in _base ""; do
+    GPV_LIB=$GRAFT_REPO_ROOT/gpvecchia_amd/libgpvecchia_hip$t.so python bench.py --mode S --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
+import sys,json
+j=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('lib[$t]', 'evals/s %.1f' % j['value'], 'ms %.4f' % j['ms_per_step'], 'set kernel %.4f' % j['roofline']['kernel_ms'], 'loglik', j['config']['loglik'])"
+  done
+done
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for t in _base ""; do
+  rm -rf $O/trace$t
+  GPV_LIB=$GRAFT_REPO_ROOT/gpvecchia_amd/libgpvecchia_hip$t.so timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace$t -- python3 bench.py --mode S --steps 10 --warmup 3 --no-cpu-baseline > $O/bench$t.json 2> $O/err$t.log
+  python3 tools/sgv_levels.py $O/trace$t > $O/levels$t.txt 2>&1
+  echo "== levels lib[$t]"; tail -3 $O/levels$t.txt
+done

@@ -22,7 +22,7 @@ tot = 0
 for i, r in enumerate(lev):
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     tot += d
-    if i < 12 or i % 16 == 0 or i == len(lev) - 1:
+    if True:
         print(i, "WPC8" if "<8>" in r["Kernel_Name"] else "WPC1", "grid", r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size"),
               "us", round(d, 1), "gap_us", round((int(r["Start_Timestamp"]) - int(lev[i - 1]["End_Timestamp"])) / 1e3, 1) if i else 0)
 print("levels", len(lev), "sum kernel us", round(tot, 1), "span us", (int(lev[-1]["End_Timestamp"]) - int(lev[0]["Start_Timestamp"])) / 1e3)
