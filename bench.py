@@ -879,10 +879,17 @@ def main():
         print(json.dumps(out), flush=True)
     rc = 0 if (check is None or check["ok"]) else 3
     if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+        # the verdict of the run is `rc`: a peer that is already gone while this rank tears its group down (gloo reports a
+        # closed connection) must not replace it
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception as e:                                # noqa: BLE001
+            print(f"[bench] rank {rank}: process group teardown: {e!r}", file=sys.stderr, flush=True)
     if rc:
-        raise SystemExit(rc)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(rc)                                          # (no interpreter teardown with half a process group)
 
 
 if __name__ == "__main__":

@@ -2142,18 +2142,38 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
     PhaseTimer tm;
     static const bool no_cache = getenv("GPV_NO_PLAN_CACHE") != nullptr;
     std::unique_lock<std::mutex> cache_lock(g_cache.mu, std::defer_lock);
-    bool cached = false;
+    bool cached = false, evaluated = false;
     if (!no_cache && *Nlocs > 0 && *dim > 0 && *ncolNN > 0) {
         cache_lock.lock();                                   // the cached plan is in use until this call returns
         const size_t nl = (size_t)*Nlocs;
-        const Hash128 hl = hash_bytes(locs, nl * (size_t)*dim * sizeof(double), 1);
-        const Hash128 hn = hash_bytes(revNNarray, nl * (size_t)*ncolNN * sizeof(int), 2);
-        const Hash128 hc = hash_bytes(revCondOnLatent, nl * (size_t)*ncolNN * sizeof(int), 3);
-        tm.lap("drop-in: content hash");
-        if (g_cache.pl && g_cache.Nlocs == *Nlocs && g_cache.dim == *dim && g_cache.ncol == *ncolNN && g_cache.h_locs == hl &&
-            g_cache.h_nn == hn && g_cache.h_cond == hc) {
+        Hash128 hl, hn, hc;
+        auto hash_all = [&]() {
+            hl = hash_bytes(locs, nl * (size_t)*dim * sizeof(double), 1);
+            hn = hash_bytes(revNNarray, nl * (size_t)*ncolNN * sizeof(int), 2);
+            hc = hash_bytes(revCondOnLatent, nl * (size_t)*ncolNN * sizeof(int), 3);
+        };
+        // The hash of the three arrays (264 MB at n = 1e6, m = 30: ~3.6 ms on 32 threads) is what proves the cached plan
+        // is the plan of THIS call.  When a plan of the right shape is cached -- every call of an optimiser run but the first
+        // -- the evaluation is started on it at once and the arrays are hashed while the kernel, the transposition and the
+        // copy of the U entries to the caller run; the outputs count only once the hash has matched, otherwise the plan is
+        // rebuilt and everything is computed again over them.
+        int rc_spec = GPV_OK;
+        const bool spec = g_cache.pl && g_cache.Nlocs == *Nlocs && g_cache.dim == *dim && g_cache.ncol == *ncolNN;
+        if (spec) {
+            std::thread hasher(hash_all);
+            rc_spec = plan_eval_impl(g_cache.pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
+            if (rc_spec == GPV_OK) rc_spec = gpv_plan_get_Lentries(g_cache.pl, Lentries);
+            hasher.join();
+            tm.lap("drop-in: content hash over nuggets H2D + kernel + transpose + D2H");
+        } else {
+            hash_all();
+            tm.lap("drop-in: content hash");
+        }
+        if (spec && g_cache.h_locs == hl && g_cache.h_nn == hn && g_cache.h_cond == hc) {
             pl = g_cache.pl;
             cached = true;
+            evaluated = true;
+            rc = rc_spec;
             ++g_cache.hits;
         } else {
             if (g_cache.pl) gpv_plan_destroy(g_cache.pl);
@@ -2171,11 +2191,13 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
         if (rc != GPV_OK) { *status = rc; return; }
     }
     tm.lap("drop-in: plan");
-    rc = plan_eval_impl(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
-    if (rc == GPV_OK && tm.on) (void)hipStreamSynchronize(pl->stream);
-    tm.lap("drop-in: nuggets H2D + kernel");
-    if (rc == GPV_OK) rc = gpv_plan_get_Lentries(pl, Lentries);
-    tm.lap("drop-in: transpose + D2H");
+    if (!evaluated) {
+        rc = plan_eval_impl(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
+        if (rc == GPV_OK && tm.on) (void)hipStreamSynchronize(pl->stream);
+        tm.lap("drop-in: nuggets H2D + kernel");
+        if (rc == GPV_OK) rc = gpv_plan_get_Lentries(pl, Lentries);
+        tm.lap("drop-in: transpose + D2H");
+    }
     double sums[GPV_NSUMS];
     if (rc == GPV_OK) rc = gpv_plan_get_sums(pl, sums);
     if (rc == GPV_OK) rc = zentries_host(pl, nuggets_obsord, *n, Zentries);

@@ -259,10 +259,12 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     double *T = tile_all + (size_t)wib * (A.ld + 2) * kTS;
     // the structure records are read once per evaluation: non-temporal, so that ~0.3 GB of them per pass do not push the
     // set kernel's index stream and location records out of the Infinity Cache between evaluations
+    // the first round's row-list records by position alone (kRC * WPC per column, this wave's 16 of them): requested FIRST and
+    // fenced, or the compiler sinks the request below the wait for the column record (it loads this kernel argument lazily)
+    const int4 rrf = nt_load(&rr0lev[(size_t)w * (kRC * WPC) + (WPC == 1 ? 0 : wib * kRC) + (lane >> 2)]);
     const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
     const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + w) + 1]);
-    // the first round's row-list records by position alone (kRC * WPC per column, this wave's 16 of them)
-    const int4 rrf = nt_load(&rr0lev[(size_t)w * (kRC * WPC) + (WPC == 1 ? 0 : wib * kRC) + (lane >> 2)]);
+    __builtin_amdgcn_sched_barrier(0);
     post_column<WPC, MODE, ZST>(A, c0, c1, rrf, T, wib, lane, MODE == 0 ? nullptr : toppart + 66 * (size_t)(first + w - top_base));
 }
 
@@ -288,9 +290,10 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
     const int wcol = (blockIdx.x * (blockDim.x >> 6) + wib) * G + g;            // this group's column of the level
     const bool live = wcol < count;
     double *T = tile_all + ((size_t)wib * G + g) * (A.ld + 2) * TSG;
-    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0))]);
+    const int4 rrf = nt_load(&rr0lev[(size_t)(live ? wcol : 0) * RCG + col]);   // first round: with the column record (fenced:
+    const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0))]);   //  see gpv_posterior_level_kernel)
     const int4 c1 = nt_load(&A.colrec[2 * (size_t)(first + (live ? wcol : 0)) + 1]);
-    const int4 rrf = nt_load(&rr0lev[(size_t)(live ? wcol : 0) * RCG + col]);   // first round: with the column record
+    __builtin_amdgcn_sched_barrier(0);
     const int k = c0.x, cnt = c0.z, nrow = cnt + 2;
     const int qb = c0.w, qe = live ? c1.x : c0.w;                               // (a group without a column runs no round)
     double2 *Ck = A.C + c0.y;

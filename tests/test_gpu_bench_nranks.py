@@ -26,6 +26,13 @@ def _bench(extra, env=None, timeout=600):
                         "--warmup", "1", "--no-cpu-baseline", "--no-secondary"] + extra,
                        capture_output=True, text=True, timeout=timeout, env=e)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    log = os.path.join(ROOT, "gpurun_out", "nranks_last_stderr.txt")      # the whole stderr of the last launch, for a failure
+    try:
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        with open(log, "w") as f:
+            f.write(f"rc {r.returncode} extra {extra} env {env}\n" + r.stderr)
+    except OSError:
+        pass
     return r, (json.loads(lines[-1]) if lines else None), time.time() - t0
 
 
