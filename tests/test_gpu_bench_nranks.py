@@ -26,7 +26,8 @@ def _bench(extra, env=None, timeout=600):
                         "--warmup", "1", "--no-cpu-baseline", "--no-secondary"] + extra,
                        capture_output=True, text=True, timeout=timeout, env=e)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
-    log = os.path.join(ROOT, "gpurun_out", "nranks_last_stderr.txt")      # the whole stderr of the last launch, for a failure
+    tag = "_".join(f"{k[10:]}-{v}" for k, v in sorted((env or {}).items())).replace(":", "-") or "plain"
+    log = os.path.join(ROOT, "gpurun_out", f"nranks_{tag}.txt")          # the whole stderr of the launch, for a failure
     try:
         os.makedirs(os.path.dirname(log), exist_ok=True)
         with open(log, "w") as f:

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r5c; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_bench_nranks.py tests/test_gpu_posterior_oracle.py -m gpu -q -k "not C5 and not 1e6" > $O/tests1.txt 2>&1
-tail -6 $O/tests1.txt; cp gpurun_out/nranks_last_stderr.txt $O/ 2>/dev/null
+tail -6 $O/tests1.txt
 for rep in 1 2 3; do
   for t in _base ""; do
     GPV_LIB=$GRAFT_REPO_ROOT/gpvecchia_amd/libgpvecchia_hip$t.so python bench.py --mode S --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
