@@ -675,8 +675,7 @@ def main():
                     z = z.copy()
                     z[a] += 1.0
                 elif int(r_bad) == rank and kind == "rows":
-                    b -= 1
-                    revNN, revCond = revNN[:-1], revCond[:-1]
+                    b -= 1                                        # (the index arrays keep their Nlocs rows: the plan reads rows a..b-1)
         plan = G.Plan(locs, revNN, revCond, device=local_rank, row_begin=a, row_end=b)
         plan.set_data(z)
         if comm is not None:

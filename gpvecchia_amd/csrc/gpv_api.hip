@@ -234,62 +234,72 @@ void sort_order_by_key(const uint64_t *key, int64_t n, int32_t *order)
     for (int64_t i = 0; i < n; ++i) order[i] = src[i].i;
 }
 
-// 128-bit content hash of a host buffer, chunks hashed by separate threads and combined in chunk order.
-// Two independent multiply-rotate lanes over 8-byte words (not cryptographic: it keys the plan cache of the literal
-// drop-in, where a false hit needs a 2^-128 collision between two different index arrays of the same shape).
+// 128-bit content hash of a host buffer.  The buffer is cut into a FIXED number of chunks (the result does not depend on
+// how many threads share them), every chunk runs eight independent multiply-rotate lanes over 64-byte blocks (every step
+// is a bijection of its lane for a given word, so a change of any single word changes the result), the chunks are
+// combined in chunk order.  Not cryptographic: it keys the plan cache of the literal drop-in, where a false hit needs a
+// collision between two different index arrays of the same shape.
 struct Hash128 {
     uint64_t a = 0, b = 0;
     bool operator==(const Hash128 &o) const { return a == o.a && b == o.b; }
 };
 inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
-Hash128 hash_bytes(const void *ptr, size_t bytes, uint64_t seed)
+Hash128 hash_bytes(const void *ptr, size_t bytes, uint64_t seed, unsigned max_threads = 32)
 {
     const unsigned char *p = static_cast<const unsigned char *>(ptr);
     const size_t words = bytes / 8;
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = hw ? (hw > 32 ? 32 : hw) : 4;
-    if (bytes < ((size_t)1 << 22)) nt = 1;
-    std::vector<Hash128> part(nt);
-    const size_t chunk = (words + nt - 1) / nt;
+    constexpr uint64_t K1 = 0xC2B2AE3D27D4EB4Full, K2 = 0x9E3779B97F4A7C15ull, K3 = 0x165667B19E3779F9ull, K4 = 0xD6E8FEB86659FD93ull;
+    const size_t nchunk = (bytes < ((size_t)1 << 22)) ? 1 : 64;
+    const size_t chunk = ((words + nchunk - 1) / nchunk + 7) / 8 * 8;    // words per chunk, whole 64-byte blocks
+    std::vector<Hash128> part(nchunk);
     auto work = [&](size_t t) {
-        const size_t lo = t * chunk, hi = (lo + chunk < words) ? lo + chunk : words;
-        uint64_t h0 = seed ^ 0x9E3779B97F4A7C15ull, h1 = seed + 0xD6E8FEB86659FD93ull;
-        uint64_t g0 = ~seed, g1 = seed * 0xFF51AFD7ED558CCDull + 1;
+        const size_t lo = t * chunk < words ? t * chunk : words, hi = (lo + chunk < words) ? lo + chunk : words;
+        uint64_t acc[8];
+        for (int l = 0; l < 8; ++l) acc[l] = (seed + (uint64_t)l) * K3 ^ rotl64(K4, 7 * l + 1);
         size_t i = lo;
-        for (; i + 2 <= hi; i += 2) {
-            uint64_t v0, v1;
-            std::memcpy(&v0, p + 8 * i, 8);
-            std::memcpy(&v1, p + 8 * i + 8, 8);
-            h0 = rotl64(h0 ^ (v0 * 0x9E3779B97F4A7C15ull), 27) * 0xC2B2AE3D27D4EB4Full;
-            h1 = rotl64(h1 ^ (v1 * 0xD6E8FEB86659FD93ull), 31) * 0x165667B19E3779F9ull;
-            g0 = rotl64(g0 + v0, 29) * 0xFF51AFD7ED558CCDull ^ v1;
-            g1 = rotl64(g1 + v1, 23) * 0xC4CEB9FE1A85EC53ull ^ v0;
+        for (; i + 8 <= hi; i += 8) {
+            uint64_t v[8];
+            std::memcpy(v, p + 8 * i, 64);
+            for (int l = 0; l < 8; ++l) acc[l] = rotl64(acc[l] + v[l] * K1, 31) * K2;
         }
-        for (; i < hi; ++i) {
+        for (int l = 0; i < hi; ++i, ++l) {
             uint64_t v0;
             std::memcpy(&v0, p + 8 * i, 8);
-            h0 = rotl64(h0 ^ (v0 * 0x9E3779B97F4A7C15ull), 27) * 0xC2B2AE3D27D4EB4Full;
-            g0 = rotl64(g0 + v0, 29) * 0xFF51AFD7ED558CCDull;
+            acc[l] = rotl64(acc[l] + v0 * K1, 31) * K2;
         }
-        part[t].a = h0 ^ rotl64(h1, 17);
-        part[t].b = g0 ^ rotl64(g1, 41);
+        uint64_t a = seed ^ K4, b = ~seed * K3;
+        for (int l = 0; l < 8; ++l) {
+            a = rotl64(a ^ acc[l], 27) * K2 + (uint64_t)l;
+            b = rotl64(b + (acc[l] ^ rotl64(acc[l], 32)), 41) * K1 ^ (uint64_t)l;
+        }
+        part[t].a = a;
+        part[t].b = b;
     };
-    if (nt == 1) work(0);
-    else {
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw ? (hw > max_threads ? max_threads : hw) : 4;
+    if (nt > nchunk) nt = nchunk;
+    if (nt <= 1) {
+        for (size_t t = 0; t < nchunk; ++t) work(t);
+    } else {
+        std::atomic<size_t> next{0};
+        auto loop = [&]() {
+            for (size_t t = next.fetch_add(1); t < nchunk; t = next.fetch_add(1)) work(t);
+        };
         std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
+        for (size_t t = 0; t + 1 < nt; ++t) th.emplace_back(loop);
+        loop();
         for (auto &x : th) x.join();
     }
     Hash128 r;
     r.a = seed ^ (uint64_t)bytes;
     r.b = ~seed + (uint64_t)bytes;
-    for (size_t t = 0; t < nt; ++t) {
-        r.a = rotl64(r.a ^ part[t].a, 25) * 0x9E3779B97F4A7C15ull + t;
-        r.b = rotl64(r.b + part[t].b, 37) * 0xC2B2AE3D27D4EB4Full ^ t;
+    for (size_t t = 0; t < nchunk; ++t) {
+        r.a = rotl64(r.a ^ part[t].a, 25) * K2 + t;
+        r.b = rotl64(r.b + part[t].b, 37) * K1 ^ t;
     }
     uint64_t tail = 0;                                        // the last bytes % 8 bytes
     std::memcpy(&tail, p + 8 * words, bytes - 8 * words);
-    r.a ^= tail * 0xD6E8FEB86659FD93ull;
+    r.a ^= tail * K4;
     r.b += rotl64(tail, 13);
     return r;
 }
@@ -2147,10 +2157,12 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
         cache_lock.lock();                                   // the cached plan is in use until this call returns
         const size_t nl = (size_t)*Nlocs;
         Hash128 hl, hn, hc;
-        auto hash_all = [&]() {
-            hl = hash_bytes(locs, nl * (size_t)*dim * sizeof(double), 1);
-            hn = hash_bytes(revNNarray, nl * (size_t)*ncolNN * sizeof(int), 2);
-            hc = hash_bytes(revCondOnLatent, nl * (size_t)*ncolNN * sizeof(int), 3);
+        // (threads: 32 when nothing else runs; 12 beside the evaluation, whose copy to the caller keeps 8 host threads and the
+        //  DMA engine busy on the same memory)
+        auto hash_all = [&](unsigned threads) {
+            hl = hash_bytes(locs, nl * (size_t)*dim * sizeof(double), 1, threads);
+            hn = hash_bytes(revNNarray, nl * (size_t)*ncolNN * sizeof(int), 2, threads);
+            hc = hash_bytes(revCondOnLatent, nl * (size_t)*ncolNN * sizeof(int), 3, threads);
         };
         // The hash of the three arrays (264 MB at n = 1e6, m = 30: ~3.6 ms on 32 threads) is what proves the cached plan
         // is the plan of THIS call.  When a plan of the right shape is cached -- every call of an optimiser run but the first
@@ -2160,13 +2172,13 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
         int rc_spec = GPV_OK;
         const bool spec = g_cache.pl && g_cache.Nlocs == *Nlocs && g_cache.dim == *dim && g_cache.ncol == *ncolNN;
         if (spec) {
-            std::thread hasher(hash_all);
+            std::thread hasher(hash_all, 12u);
             rc_spec = plan_eval_impl(g_cache.pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
             if (rc_spec == GPV_OK) rc_spec = gpv_plan_get_Lentries(g_cache.pl, Lentries);
             hasher.join();
             tm.lap("drop-in: content hash over nuggets H2D + kernel + transpose + D2H");
         } else {
-            hash_all();
+            hash_all(32u);
             tm.lap("drop-in: content hash");
         }
         if (spec && g_cache.h_locs == hl && g_cache.h_nn == hn && g_cache.h_cond == hc) {

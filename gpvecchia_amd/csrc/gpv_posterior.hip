@@ -84,6 +84,18 @@ __device__ __forceinline__ double post_rcp(const double x)
     return (r == r) ? r : r0;
 }
 
+// Which workgroup of the level's list a hardware workgroup takes.  Workgroups go round-robin over the 8 XCDs (workgroup b to
+// XCD b % 8), each with an L2 of its own, and the wide levels are bound by the 128-byte lines they miss there (tools/ubench/
+// gather_lines.hip: a scattered gather costs one line whatever it uses of it, ~54 lines per ns for the chip): columns that
+// are neighbours in the level's Morton order gather from the same blocks, so XCD x takes the x-th CONTIGUOUS eighth of the
+// list and what one column brings into its L2 serves the next.  A bijection on [0, nb) for any nb; where the hardware maps
+// differently only the hit rate changes, never the result.
+__device__ __forceinline__ int xcd_block(const int b, const int nb)
+{
+    const int q = nb >> 3, r = nb & 7, x = b & 7, i = b >> 3;
+    return x * q + (x < r ? x : r) + i;
+}
+
 // One column of the factor.  c0, c1: its column record.
 // MODE 1 (the columns of the dense top block, gpv_posterior_top_kernel): no pivot, the column's sums (64 rows, z2, s) go to
 // tpart; the row-list entries flagged in rowrec.w are the other top columns, whose R and t do not exist yet: their
@@ -254,7 +266,7 @@ __global__ void __launch_bounds__(WPC == 1 ? 256 : 64 * WPC) gpv_posterior_level
     extern __shared__ double tile_all[];
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int w = (WPC == 1) ? (blockIdx.x * (blockDim.x >> 6)) + wib : blockIdx.x;
+    const int w = (WPC == 1) ? (xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6)) + wib : blockIdx.x;
     if (WPC == 1 && w >= count) return;
     double *T = tile_all + (size_t)wib * (A.ld + 2) * kTS;
     // the structure records are read once per evaluation: non-temporal, so that ~0.3 GB of them per pass do not push the
@@ -287,7 +299,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int g = lane / LPC, l = lane % LPC;
     const int col = l >> 2, sub = l & (kSub - 1);
-    const int wcol = (blockIdx.x * (blockDim.x >> 6) + wib) * G + g;            // this group's column of the level
+    const int wcol = (xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + wib) * G + g;   // this group's column of the level
     const bool live = wcol < count;
     double *T = tile_all + ((size_t)wib * G + g) * (A.ld + 2) * TSG;
     const int4 rrf = nt_load(&rr0lev[(size_t)(live ? wcol : 0) * RCG + col]);   // first round: with the column record (fenced:
@@ -427,7 +439,7 @@ hipError_t launch_posterior_compact(const double *L, int ld, const double *avec,
 // n = 1e6.  (Several columns per 16-lane group with the next record prefetched: 43.4-47.3 us for 2-16 columns, not kept.)
 __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs A, int first, int count)
 {
-    const int w = (int)((blockIdx.x * 256 + threadIdx.x) >> 4), sub = threadIdx.x & 15;
+    const int w = (int)((xcd_block(blockIdx.x, gridDim.x) * 256 + threadIdx.x) >> 4), sub = threadIdx.x & 15;
     if (w >= count) return;
     const int4 c0 = nt_load(&A.colrec[2 * (size_t)(first + w)]);
     const int k = c0.x, cnt = c0.z;
@@ -1049,7 +1061,7 @@ template <int LPC>
 __global__ void __launch_bounds__(256) gpv_mean_level_rec_kernel(const PostArgs A, const int4 *meanrec, double *u, int first, int count)
 {
     const int lane = threadIdx.x & 63, l = lane % LPC;
-    const int w = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LPC) + lane / LPC;
+    const int w = (xcd_block(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6)) * (64 / LPC) + lane / LPC;
     const bool live = w < count;
     const int4 rec = nt_load(&meanrec[first + (live ? w : 0)]);
     const int k = rec.x, cnt = rec.z;

@@ -49,6 +49,9 @@
 #ifndef GPV_RPL2_MAXP
 #define GPV_RPL2_MAXP 41        // two rows per lane for 24 <= P <= this (measured: -23 % at P=41, +6 % at P=51)
 #endif
+#ifndef GPV_RPL2_MINP
+#define GPV_RPL2_MINP 24        // (LDS path) ... and from this row length on
+#endif
 #ifndef GPV_COV_UNROLL
 #define GPV_COV_UNROLL 2       // unroll factor of the covariance rounds
 #endif
@@ -130,7 +133,7 @@ template <int P>
 struct Geo {
     static constexpr bool DPP2 = k_dpp2(P);
     static constexpr bool DPP = k_dpp(P) || DPP2;
-    static constexpr int RPL = DPP2 ? 2 : (DPP ? (P + 15) / 16 : ((P >= 24 && P <= GPV_RPL2_MAXP) ? 2 : 1));   // rows per lane (LDS path: measured, pays from P ~ 24)
+    static constexpr int RPL = DPP2 ? 2 : (DPP ? (P + 15) / 16 : ((P >= GPV_RPL2_MINP && P <= GPV_RPL2_MAXP) ? 2 : 1));   // rows per lane (LDS path: measured, pays from P ~ 24)
     static constexpr int LPS0 = (P + RPL - 1) / RPL;                            // lanes per set, minimal
     // one more lane per set when it costs no set per wave: guarantees a spare row slot for the data row
     static constexpr int LPS = DPP2 ? 32 : (DPP ? 16 : ((LPS0 * RPL == P && LPS0 < 64 && 64 / (LPS0 + 1) == 64 / LPS0) ? LPS0 + 1 : LPS0));
