@@ -248,7 +248,10 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     const double accd = __shfl(acc, cnt - 1, 64) + itau;
     double rkk, rinv;
     top_pivot(accd, rkk, rinv);
-    if (lane < cnt) Ck[1 + lane].y = (lane == cnt - 1) ? rkk : top_div(acc, rkk, rinv);
+    // (B, R) stored as the whole 16-byte pair, B as it was read: neighbouring lanes then fill whole sectors of the block; an
+    // 8-byte store of R alone leaves every sector partially written, which the memory behind the L2 can only merge by
+    // reading it first
+    if (lane < cnt) Ck[1 + lane] = make_double2(bk_own, (lane == cnt - 1) ? rkk : top_div(acc, rkk, rinv));
     if (lane == 0) {
         z2 = __builtin_fma(-zk, itau, z2);           // observed column of U: (-1/sqrt(tau)) * (z_k/sqrt(tau))
         const double t = top_div(z2 - s, rkk, rinv);
@@ -395,7 +398,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int r = l + j * LPC;
-        if (r < cnt) Ck[1 + r].y = (r == cnt - 1) ? rkk : top_div(acc[j], rkk, rinv);
+        if (r < cnt) Ck[1 + r] = make_double2(bk_own[j], (r == cnt - 1) ? rkk : top_div(acc[j], rkk, rinv));   // whole pairs: see post_column
     }
     if (l == 0) {
         const double z2 = __builtin_fma(-zk, itau, __builtin_fma(dk, ak_own, z2raw));
@@ -456,7 +459,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_leaf_kernel(const PostArgs 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int e = sub + 16 * j;
-        if (e < cnt) Ck[1 + e].y = (e == cnt - 1) ? rkk : top_div(__builtin_fma(b[j], dk, 0.0), rkk, rinv);
+        if (e < cnt) Ck[1 + e] = make_double2(b[j], (e == cnt - 1) ? rkk : top_div(__builtin_fma(b[j], dk, 0.0), rkk, rinv));   // whole pairs: see post_column
     }
     if (sub == 0) {
         const double z2 = __builtin_fma(-zk, itau, __builtin_fma(dk, ak, 0.0));

@@ -52,7 +52,15 @@ for i in (1, 2, 3, 4):
         if int(r["Dispatch_Id"]) == last:
             tot[r["Counter_Name"]] = tot.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 b = json.loads(line)
+# the sets ONE launch of THIS process handles: a rank's row shard when the bench line says so (sharding "rows/N", or the
+# emulated per-rank load of --emulate-world E), not the whole data set
 nsets = b["config"]["n"]
+shard = str(b["config"].get("sharding", "rows/1")).split("/")[-1]
+if shard.isdigit() and int(shard) > 1:
+    nsets = nsets // int(shard)
+spl = b.get("roofline", {}).get("sets_per_launch")
+if spl:
+    nsets = int(spl)
 if "GRBM_GUI_ACTIVE" in tot:
     cyc = tot["GRBM_GUI_ACTIVE"] / 8
     tot["_derived"] = {
