@@ -112,3 +112,37 @@ def test_posterior_pass_against_sparse_oracle_modeS_n1e6_m30():
     z = np.random.default_rng(1).standard_normal(n)
     res = _compare(G, locs, z, m, [1.0, 0.02, 1.5], 0.1, 60)
     assert not res["adjudicated"]
+
+
+@pytest.mark.parametrize("cond,ordering_pred", [("SGV", "obspred"), ("SGVT", "obspred"), ("zy", "obspred")])
+def test_prediction_plan_against_sparse_oracle_n4e4(cond, ordering_pred):
+    """Plans WITH prediction locations at a size the dense restatement cannot hold (4e4 observations + 1e4 prediction
+    locations, m = 15): createU with unobserved rows, U2V's obs-pred branch (R/vecchia_prediction.R:84-107) or the 'zy' branch
+    (:68-70), vecchia_mean with mu.pred (:118-142), all from the oracle's sparse restatement; the HIP side is
+    vecchia_prediction (device route for SGV: gpv_plan_set_observed) and vecchia_likelihood.  (cond.yz = 'y' stays with the
+    dense restatement's sizes, tests/test_gpu_prediction.py: its natural-order factor fills in -- 17 M entries at n = 8000.)"""
+    import warnings
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, n_p, m = 40_000, 10_000, 15
+    rng = np.random.default_rng(11)
+    locs, lp = rng.random((n, 2)), rng.random((n_p, 2))
+    z = np.sin(6 * locs[:, 0]) * np.cos(5 * locs[:, 1]) + 0.3 * rng.standard_normal(n)
+    tau = 0.05 + 0.1 * rng.random(n)
+    cp = [1.0, 0.05, 1.5]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond, locs_pred=lp, ordering_pred=ordering_pred)
+        ll = G.vecchia_likelihood(z, va, cp, tau)
+        pred = G.vecchia_prediction(z, va, cp, tau)
+    Us = R.createU_sparse(_to_oracle_va(va), cp, tau)
+    V = R.U2V_sparse(Us)
+    ll_ref = R.vecchia_likelihood_U_sparse(z, Us, V=V)
+    mo_ref, mp_ref = R.vecchia_mean_sparse(z, Us, V, both=True)
+    assert abs(ll - ll_ref) <= RTOL * abs(ll_ref), (ll, ll_ref)
+    scale = max(1.0, np.abs(mo_ref).max())
+    assert pred["mu_obs"].shape == (n,) and pred["mu_pred"].shape == (n_p,)
+    np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=RTOL * scale)
+    np.testing.assert_allclose(pred["mu_pred"], mp_ref, rtol=0, atol=RTOL * scale)
+    if cond == "SGV":
+        assert pred.get("route") == "device"
