@@ -89,6 +89,7 @@ def lib():
     L.gpv_plan_get_Zentries.argtypes = [vp, dp]
     L.gpv_plan_Lentries_device.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
     L.gpv_plan_rows.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+    L.gpv_plan_dims.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.gpv_plan_last_kernel_ms.argtypes = [vp, dp]
     L.gpv_plan_set_kernel_timing.argtypes = [vp, C.c_int]
     L.gpv_loglik_z_from_sums.argtypes = [dp, i64, dp]

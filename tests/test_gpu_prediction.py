@@ -271,3 +271,36 @@ def test_set_observed_argument_rules():
     assert np.isfinite(mu_all).all() and not np.allclose(mu_all, mu_masked)
     with pytest.raises(ValueError):
         plan.set_observed(np.ones(3, bool))
+
+
+def test_masked_nuggets_stay_out_of_the_callers_view_and_plan_dims():
+    """With unobserved locations set, the posterior pass reads +Inf nuggets there (no 1/tau in W) from a buffer of its own:
+    what the caller handed in is what Zentries and a later evaluation without a pass see (round 4 masked it in place).
+    gpv_plan_dims returns the shape the plan was created with."""
+    import ctypes as C
+    G = _need_gpu()
+    from gpvecchia_amd import _lib as L
+    rng = np.random.default_rng(9)
+    n, n_p, m = 400, 150, 6
+    locs, lp = rng.random((n, 1)), rng.random((n_p, 1))
+    va = G.vecchia_specify(locs, m, locs_pred=lp)
+    from gpvecchia_amd import api as A
+    plan = A._plan_for(va)
+    nl, dim, p = C.c_int64(), C.c_int(), C.c_int()
+    L.check(L.lib().gpv_plan_dims(plan._h, C.byref(nl), C.byref(dim), C.byref(p)), "gpv_plan_dims")
+    assert (nl.value, dim.value, p.value) == (n + n_p, 1, m + 1)
+    assert L.lib().gpv_plan_dims(None, C.byref(nl), None, None) == 2           # GPV_ERR_BAD_ARG
+    assert plan.build_posterior_fill() is not None
+    obs = np.asarray(va["obs"], bool)
+    z = np.zeros(n + n_p); z[obs] = rng.standard_normal(n)
+    plan.set_data(z)
+    plan.set_observed(va["obs"])
+    nug = np.where(obs, 0.05 + 0.1 * rng.random(n + n_p), 0.0)
+    plan.eval("matern", [1.0, 0.05, 0.5], nug, G.GPV_WANT_MEAN | G.GPV_WANT_U)
+    assert np.isfinite(plan.posterior_mean()).all()
+    Z = plan.Zentries()                                                # from the caller's nuggets: +-1/sqrt(tau), Inf where tau = 0
+    with np.errstate(divide="ignore"):
+        ref = 1.0 / np.sqrt(nug)
+    np.testing.assert_allclose(Z[1::2], ref, rtol=1e-15)
+    np.testing.assert_allclose(Z[0::2], -ref, rtol=1e-15)
+    assert np.isinf(Z[1::2][~obs]).all()                               # (masked in place they would be 1/sqrt(Inf) = 0)
