@@ -55,6 +55,22 @@ class Plan:
         L.check(L.lib().gpv_plan_posterior_levels(self._h, C.byref(nl)), "gpv_plan_posterior_levels")
         return int(nl.value)
 
+    def ensure_posterior(self):
+        """True when the structure of the device posterior pass exists (built now if it did not); False when the library
+        refuses it for this plan (GPV_ERR_UNSUPPORTED_M: some conditioning set has more than 64 LATENT entries; the row
+        length m + 1 itself may exceed 64): the caller then takes the host route, like the reference's CHOLMOD."""
+        if self.has_posterior:
+            return True
+        if getattr(self, "_post_refused", False):
+            return False
+        st = L.lib().gpv_plan_build_posterior(self._h, L.iptr(self._nn), L.iptr(self._cd))
+        if st == 5:
+            self._post_refused = True
+            return False
+        L.check(st, "gpv_plan_build_posterior")
+        self.has_posterior = True
+        return True
+
     def build_posterior_fill(self, max_fill=4.0):
         """Structure of the U2V pass on the FILLED pattern (cond.yz='y': the factor fills in, R/vecchia_prediction.R:72-83).
         Returns the fill ratio, or None when the library refuses (fill beyond max_fill x the latent block, or a column of the
@@ -890,17 +906,16 @@ def vecchia_likelihood(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_LOGLIK_Z)
         return loglik_z_from_sums(plan.sums(), n)
     if plain and va["cond_yz"] == "SGV" and isinstance(covmodel, str) and not np.any(nug == 0) and \
-            va["U_prep"]["revNNarray"].shape[1] <= 64:                      # ic0 changes nothing: no fill
+            _plan_for(va, device).ensure_posterior():                       # ic0 changes nothing: no fill
         # default mode: U, the numerator AND the posterior pass (U2V) on the GPU; SGV has no fill, so the
-        # fixed-pattern factorisation equals the reference's Matrix::chol (R/vecchia_prediction.R:80)
+        # fixed-pattern factorisation equals the reference's Matrix::chol (R/vecchia_prediction.R:80).  (Refused only
+        # when a conditioning set has more than 64 latent entries: the host route below.)
         plan = _plan_for(va, device)
-        if not plan.has_posterior:
-            plan.build_posterior()
         plan.set_user_data(z, va["ord_z"])
         plan.eval(covmodel, covparms, _device_nuggets(va, nug), GPV_WANT_DENOM)
         return loglik_from_sums(plan.sums(), n)
     if plain and va["cond_yz"] == "y" and isinstance(covmodel, str) and not np.any(nug == 0) and \
-            va["U_prep"]["revNNarray"].shape[1] <= 64 and not va.get("ic0", False):
+            not va.get("ic0", False):
         # latent conditioning throughout: W = U_y U_y^T fills in.  The device pass runs on the filled pattern when the fill is
         # bounded (symbolic factorisation on the host, once per plan); otherwise the host factorisation below, like CHOLMOD
         plan = _plan_for(va, device)

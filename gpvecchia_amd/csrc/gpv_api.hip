@@ -1186,7 +1186,6 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
     for (auto &g : pl->pgraph)
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
     if (pl->row_begin != 0 || pl->row_end != pl->Nlocs) return GPV_ERR_BAD_ARG;   // not shardable
-    if (pl->p > 64) return GPV_ERR_UNSUPPORTED_M;      // the level kernels own one lane per row of a column (<= 64)
     if (pl->Nlocs >= (int64_t)1 << 31) return GPV_ERR_BAD_ARG;
     const int64_t n = pl->Nlocs;
     const int p = pl->p;
@@ -1227,7 +1226,12 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
             }
         }
     }
-    int maxcnt = p;
+    // the level kernels own one lane per row of a column: at most 64 LATENT entries per conditioning set (the row length
+    // m + 1 itself may be larger: under SGV about a third of a set is conditioned on as latent)
+    int maxlat = 0;
+    for (int64_t k = 0; k < n; ++k) maxlat = std::max(maxlat, (int)(colptr[(size_t)k + 1] - colptr[(size_t)k]));
+    if (maxlat > 64) return GPV_ERR_UNSUPPORTED_M;
+    int maxcnt = p <= 64 ? p : maxlat;
     if (with_fill) {
         // cond.yz = 'y' (R/vecchia_prediction.R:72-83): W = B B^T + D^-1 couples every two rows of a column, and the UL factor
         // R (= what t(chol(rev(W))) holds, reversed) fills in beyond the pattern of B.  Symbolic factorisation, last column
@@ -1292,7 +1296,7 @@ static int build_posterior_impl(gpv_plan *pl, const int *revNN, const int *revCo
         crow.swap(crow2);
         cslot.swap(cslot2);
     }
-    pl->post_ld = maxcnt > pl->P ? maxcnt : pl->P;
+    pl->post_ld = (pl->P <= 64 && maxcnt < pl->P) ? pl->P : maxcnt;     // bound of the entries per column (LDS tiles are sized by it)
     const size_t nnz = crow.size();
     for (size_t e = 0; e < nnz; ++e) rowcnt[(size_t)crow[e] + 1]++;
     std::vector<int32_t> rowptr((size_t)n + 1, 0);

@@ -1457,7 +1457,11 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                 const bool good = set_on && !fail;
                 const double tau = nugraw[QO];
                 const double zk = zi[QO];
-                if (aout != nullptr && set_on && i == IO) aout[want_row ? row_out : rowid[k]] = fail ? 0.0 : negmu * rs;
+                // a_k: into the head of the set's compact block (fused deposit: the posterior pass reads it there) or into the
+                // a vector (the compaction launch and the 'zy' mean, whose t IS a, read that); never both: the vector's entry
+                // is an 8-byte store to a line of its own per set
+                const bool a_to_vec = !fused || (A.flags & kFlagBoth) != 0;
+                if (aout != nullptr && a_to_vec && set_on && i == IO) aout[want_row ? row_out : rowid[k]] = fail ? 0.0 : negmu * rs;
                 if (fused && set_on && i == IO) Cout[cb] = v2d_out{fail ? 0.0 : negmu * rs, 0.0};
                 if (A.flags & 2) {
                     const double tv = tau + vlast;

@@ -71,27 +71,23 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
     va = vecchia_approx
     z, nug = A._removeNAs(z, nuggets)
     n = int(np.sum(va["obs"]))
-    plain = (n == va["locsord"].shape[0]) and va["cond_yz"] in ("SGV", "z", "false") and \
-        va["U_prep"]["revNNarray"].shape[1] <= 64                           # the device posterior pass handles m + 1 <= 64
-    if plain and isinstance(covmodel, str) and not np.any(nug == 0):
+    plain = (n == va["locsord"].shape[0]) and va["cond_yz"] in ("SGV", "z", "false")
+    # (the device posterior pass takes any m as long as no conditioning set has more than 64 latent entries)
+    if plain and isinstance(covmodel, str) and not np.any(nug == 0) and A._plan_for(va, device).ensure_posterior():
         plan = A._plan_for(va, device)
-        if not plan.has_posterior:
-            plan.build_posterior()
         plan.set_data(z[va["ord_z"] - 1])
         plan.eval(covmodel, covparms, A._device_nuggets(va, nug), GPV_WANT_MEAN)
         mu = np.empty(n)
         mu[va["ord"] - 1] = plan.posterior_mean()                         # orig.order = order(U.obj$ord), :135-136
         return dict(mu_obs=mu, mu_pred=np.empty(0), var_obs=None, var_pred=None)
     if (va["cond_yz"] == "zy" and isinstance(covmodel, str) and not np.any(nug == 0)
-            and va["U_prep"]["revNNarray"].shape[1] <= 64):
+            and A._plan_for(va, device).ensure_posterior()):
         # the reference's default with prediction locations in two or more dimensions (R/vecchia_specify.R:92-96).  V.ord is
         # the reversed latent block of U (R/vecchia_prediction.R:68-70): set kernel + ONE level-scheduled triangular solve
         # on the GPU (GPV_WANT_MEAN_B), nothing on the host
         from ._lib import GPV_WANT_MEAN_B
         nrows = va["locsord"].shape[0]                                   # n dummy rows + n latent-at-observed + prediction rows
         plan = A._plan_for(va, device)
-        if not plan.has_posterior:
-            plan.build_posterior()
         zpad = np.zeros(nrows)
         zpad[:n] = z[va["ord_z"] - 1]
         plan.set_data(zpad)
@@ -103,7 +99,7 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         return dict(mu_obs=mu_obs, mu_pred=mu_pred, var_obs=None, var_pred=None)
     nrows = va["locsord"].shape[0]
     if (n < nrows and va["cond_yz"] in ("SGV", "SGVT", "y") and isinstance(covmodel, str) and not np.any(nug == 0)
-            and not va.get("ic0", False) and va["U_prep"]["revNNarray"].shape[1] <= 64 and nug.size in (1, n)):
+            and not va.get("ic0", False) and nug.size in (1, n)):
         # prediction locations with latent conditioning (the reference's default in one dimension, R/vecchia_specify.R:92-96):
         # both branches of U2V that factorise (:72-107) are ONE factorisation W = R R^T with no 1/tau at the unobserved
         # locations (gpv_plan_set_observed): with ordering.pred = 'obspred' R = B on the prediction columns, which is the
@@ -113,7 +109,7 @@ def vecchia_prediction(z, vecchia_approx, covparms, nuggets, covmodel="matern", 
         plan = A._plan_for(va, device)
         if not plan.has_posterior:
             if va["cond_yz"] in ("SGV", "SGVT") and va["ord_pred"] == "obspred":
-                plan.build_posterior()       # no fill: R = B on the prediction columns, the observed block is plain SGV
+                plan.ensure_posterior()      # no fill: R = B on the prediction columns, the observed block is plain SGV
             else:
                 plan.build_posterior_fill()
         if plan.has_posterior:
@@ -162,9 +158,9 @@ def vecchia_laplace_prediction(vl_posterior, vecchia_approx, covparms, pred_mean
 _DEVICE_MODELS = {"gaussian": 0, "logistic": 1, "poisson": 2, "gamma": 3, "beta": 4, "gamma_alt": 5}   # position in the list of :32
 
 
-def _device_loop_applies(z, va, model, covmodel):
+def _device_loop_applies(z, va, model, covmodel, device=0):
     return (model in _DEVICE_MODELS and isinstance(covmodel, str) and va["cond_yz"] in ("SGV", "z")
-            and int(np.sum(va["obs"])) == len(z) and va["U_prep"]["revNNarray"].shape[1] <= 64)
+            and int(np.sum(va["obs"])) == len(z) and A._plan_for(va, device).ensure_posterior())
 
 
 def _posterior_VL_device(z, va, model, covparms, covmodel, likparms, max_iter, convg, y_init, prior_mean, fam, verbose, device,
@@ -248,11 +244,12 @@ def calculate_posterior_VL(z, vecchia_approx, likelihood_model="gaussian", covpa
     prior_mean = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, dtype=np.float64)
     y_o = prior_mean.copy() if y_init is None or np.any(np.isnan(y_init)) else np.asarray(y_init, float).copy()   # :81-82
     va = vecchia_approx
-    if on_device is not False and _device_loop_applies(z, va, likelihood_model, covmodel) and obs_inds.size >= 2:
+    if on_device is not False and obs_inds.size >= 2 and _device_loop_applies(z, va, likelihood_model, covmodel, device):
         return _posterior_VL_device(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, y_o, prior_mean,
                                     fam, verbose, device, want_vectors=_want_vectors)
     if on_device is True:
-        raise ValueError("on_device=True needs cond.yz in {'SGV','z'}, no prediction locations and m + 1 <= 64")
+        raise ValueError("on_device=True needs cond.yz in {'SGV','z'}, no prediction locations and at most 64 latent entries "
+                         "per conditioning set")
     if len(y_o) > 1:
         y_o = y_o[obs_inds]                                               # :84
     pm_obs = prior_mean[obs_inds]

@@ -109,28 +109,58 @@ def test_repeated_launches_are_bit_identical(m, d, n):
             assert np.array_equal(plan.Lentries(), L0), it
 
 
-@pytest.mark.parametrize("seed", range(16))
-def test_posterior_pass_random_plans_against_host_route(seed):
+def _oracle_va(va):
+    prep = dict(va["U_prep"])
+    nn = prep["revNNarray"]
+    prep["revNNarray"] = np.where(nn == 0, np.nan, nn.astype(np.float64))
+    prep["revCond"] = np.where(prep["revCond"] < 0, np.nan, prep["revCond"].astype(np.float64))
+    out = {k: v for k, v in va.items() if not isinstance(k, tuple)}
+    out["U_prep"] = prep
+    return out
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_posterior_pass_random_plans_against_the_oracle(seed):
     """The posterior pass (factor with its dense top block, denominator, posterior mean) on random plans whose sizes straddle
-    the block's limits of 64 and 128 columns, against the host route (createU + sparse LU, what the reference's Matrix calls
-    do): R/vecchia_prediction.R:62-83,118-126, R/vecchia_likelihood.R:85-90.  tools/fuzz_posterior.py is the same over 1000
-    seeds (profiles/r04_posterior_fuzz.txt)."""
+    the block's limits of 64 and 128 columns, and a few of 2e4 - 6e4 points, against the ORACLE's sparse restatement of
+    createU -> U2V -> vecchia_likelihood_U / vecchia_mean (R/vecchia_prediction.R:62-83,118-126, R/vecchia_likelihood.R:85-90)
+    and, as a second opinion, the product's own host route (SuperLU).  A mean beyond the flat 1e-8 is adjudicated in
+    extended precision like everywhere else.  tools/fuzz_posterior.py: 1000 seeds against the host route
+    (profiles/r04_posterior_fuzz.txt)."""
     G = _need_gpu()
     from gpvecchia_amd import api as A
+    from oracle import r_side as R
     rng = np.random.default_rng(1000 + seed)
-    d = int(rng.integers(1, 4))
-    n = int([rng.integers(5, 64), rng.integers(64, 130), rng.integers(130, 400), rng.integers(400, 3000)][seed % 4])
+    big = seed >= 20
+    d = 2 if big else int(rng.integers(1, 4))
+    n = int(rng.integers(20_000, 60_000)) if big else \
+        int([rng.integers(5, 64), rng.integers(64, 130), rng.integers(130, 400), rng.integers(400, 3000)][seed % 4])
     m = int(min(n - 1, rng.integers(2, 45)))
     locs = rng.random((n, d))
     z = rng.standard_normal(n)
     nu = 0.5 if d == 1 else float(rng.choice([0.5, 1.5, 2.5]))
-    cp = [float(0.5 + rng.random()), float(0.05 + 0.3 * rng.random()), nu]
+    cp = [float(0.5 + rng.random()), float(0.05 + 0.3 * rng.random()) * (0.1 if big else 1.0), nu]
     tau = 0.05 + 0.3 * rng.random(n) if rng.random() < 0.7 else float(0.05 + 0.3 * rng.random())
-    va = G.vecchia_specify(locs, m, ordering=str(rng.choice(["maxmin", "none"])), cond_yz=str(rng.choice(["SGV", "SGV", "y"])))
+    cond = "SGV" if big else str(rng.choice(["SGV", "SGV", "y"]))
+    va = G.vecchia_specify(locs, m, ordering=str(rng.choice(["maxmin", "none"])), cond_yz=cond)
     ll = G.vecchia_likelihood(z, va, cp, tau)
     pred = G.vecchia_prediction(z, va, cp, tau)
-    U_obj = A.createU(va, cp, tau)
-    ll_h = A.vecchia_likelihood_U(z, U_obj)
-    mo_h, _ = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)
-    assert abs(ll - ll_h) <= 1e-9 * max(abs(ll_h), 1.0)
-    np.testing.assert_allclose(pred["mu_obs"], mo_h, rtol=0, atol=1e-8 * max(np.abs(mo_h).max(), 1e-300))
+    ova = _oracle_va(va)
+    Us = R.createU_sparse(ova, cp, tau)
+    V = R.U2V_sparse(Us)
+    ll_o = R.vecchia_likelihood_U_sparse(z, Us, V=V)
+    mo_o = R.vecchia_mean_sparse(z, Us, V)
+    scale = max(np.abs(mo_o).max(), 1e-300)
+    if not (abs(ll - ll_o) <= 1e-8 * max(abs(ll_o), 1.0) and np.abs(pred["mu_obs"] - mo_o).max() <= 1e-8 * scale):
+        ex = R.posterior_extended(z, ova, cp, tau)
+        mu_ext = np.empty(n)
+        mu_ext[va["ord"] - 1] = ex["mu_ord"]
+        err_hip, err_or = np.abs(pred["mu_obs"] - mu_ext).max() / scale, np.abs(mo_o - mu_ext).max() / scale
+        assert err_hip <= max(4.0 * err_or, 1e-8), (seed, err_hip, err_or)
+        assert abs(ll - ex["loglik"]) <= max(4.0 * abs(ll_o - ex["loglik"]), 1e-8 * max(abs(ll_o), 1.0)), (seed, ll, ll_o, ex["loglik"])
+    if not big:
+        U_obj = A.createU(va, cp, tau)
+        ll_h = A.vecchia_likelihood_U(z, U_obj)
+        mo_h, _ = A.split_mean(A.vecchia_mean_host(z, U_obj), U_obj)
+        assert abs(ll - ll_h) <= 1e-9 * max(abs(ll_h), 1.0)
+        np.testing.assert_allclose(pred["mu_obs"], mo_h, rtol=0, atol=1e-8 * max(np.abs(mo_h).max(), 1e-300))

@@ -304,3 +304,29 @@ def test_masked_nuggets_stay_out_of_the_callers_view_and_plan_dims():
     np.testing.assert_allclose(Z[1::2], ref, rtol=1e-15)
     np.testing.assert_allclose(Z[0::2], -ref, rtol=1e-15)
     assert np.isinf(Z[1::2][~obs]).all()                               # (masked in place they would be 1/sqrt(Inf) = 0)
+
+
+def test_device_posterior_for_long_rows_when_the_latent_entries_fit():
+    """The level kernels own one lane per LATENT entry of a conditioning set (<= 64), not per entry: a cond.yz = 'z' plan
+    with m + 1 = 71 (the generic set kernel) takes the device route for its posterior mean; 'SGV' with the same m has sets
+    of up to 71 latent entries (the first m points condition on all their predecessors) and is refused to the host route.
+    Both against the oracle."""
+    G = _need_gpu()
+    from gpvecchia_amd import api as A
+    from oracle import r_side as R
+    rng = np.random.default_rng(21)
+    n, m = 1500, 70
+    locs = rng.random((n, 2))
+    z = rng.standard_normal(n)
+    tau = 0.05 + 0.2 * rng.random(n)
+    cp = [1.1, 0.15, 1.5]
+    for cond, on_device in (("z", True), ("SGV", False)):
+        va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+        vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+        pred = G.vecchia_prediction(z, va, cp, tau)
+        assert A._plan_for(va).has_posterior == on_device, cond
+        mo_ref = R.vecchia_prediction_mean(z, vb, cp, tau)
+        np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
+        ll = G.vecchia_likelihood(z, va, cp, tau)
+        ll_ref = R.vecchia_likelihood(z, vb, cp, tau)
+        assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
