@@ -126,7 +126,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
     const int srow = two ? (lane & 31) : lane, shalf = two ? (lane >> 5) : 0;
 
     double acc = 0.0, z2 = 0.0, s = 0.0;
-    bool first_round = true;
+    int4 rr_cur = rrf;                               // the records of the round about to run
     for (int base = qb + kRC * ((WPC == 1) ? 0 : wib); base < qe; base += kRC * WPC) {
         const int q = base + col;
         // One trip for everything the round reads behind the row-list record: the (a_c, t_c) head, the (B_kc, R_kc) pair, and
@@ -137,9 +137,7 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         // leave together with the loads of the column's own block.
         constexpr int EC = GPV_POST_EC;
         const bool act = q < qe;
-        int4 rr = rrf;
-        if (!first_round) rr = nt_load(&A.rowrec[act ? q : base]);
-        first_round = false;
+        const int4 rr = rr_cur;
         const double2 *Cc = A.C + rr.x;
         const int ne = act ? (rr.z >> 8) : 0;   // entries of column c with row <= k (0 for c = k): all rows of column k (SGV cliques)
         const int tb = rr.y;
@@ -151,6 +149,13 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
             const int e = sub + u * kSub;
             pv[u] = (int)__builtin_nontemporal_load(&A.tp[tb + (e < ne ? e : 0)]);
             br[u] = Cc[1 + (e < ne ? e : 0)];
+        }
+        // the NEXT round's records travel with this round's gathers (requested unconditionally, the index clamped into the
+        // list: a conditional request is patched up by the compiler behind a full wait): rounds 2, 3, .. of a long row list
+        // then cost one trip to memory each, not two in a row
+        {
+            const int nb = base + kRC * WPC;
+            rr_cur = nt_load(&A.rowrec[(nb + col < qe) ? nb + col : ((nb < qe) ? nb : qb)]);
         }
         double Bk = 0.0, Rk = 0.0;
         bool rk_on = false;
@@ -210,6 +215,9 @@ __device__ __forceinline__ void post_column(const PostArgs &A, const int4 c0, co
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // (every word of the prefetched record stays "used" until here: a word nothing reads gets its register handed to
+        //  another value straight behind the load, which then waits for ALL loads before it may write it)
+        asm volatile("" ::"v"(rr_cur.x), "v"(rr_cur.y), "v"(rr_cur.z), "v"(rr_cur.w));
     }
     if constexpr (!ZST) {
 #pragma unroll
