@@ -1055,16 +1055,6 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
         }
         if (!launched) GPV_HIP(enqueue());                               // inside someone else's capture, or graphs off
         if (want_mean || mean_b) pl->have_mean = true;
-        // The totals reach the host as the set kernel's own do in the modes without a pass: a 64-thread kernel behind the pass
-        // stores them into the plan's pinned buffer followed by this evaluation's sequence number, and gpv_plan_get_sums
-        // spins on that number instead of sleeping in hipStreamSynchronize until an interrupt wakes it.  Outside the graph: a
-        // captured sequence number would be the same at every replay.
-        // (not for the steps of the Vecchia-Laplace loop, n_nuggets == -1: nobody reads their totals)
-        if (!mean_b && n_nuggets != -1 && d_sums_out == nullptr && !cm && !no_seq && cap == hipStreamCaptureStatusNone) {
-            ++pl->seq;
-            GPV_HIP(launch_publish_sums(pl->d_sums, pl->h_sums_dev, seq_cells, pl->seq, st));
-            pl->sums_by_seq = true;
-        }
     }
     pl->evaluated = true;
     pl->have_U = (flags & GPV_WANT_U) != 0;

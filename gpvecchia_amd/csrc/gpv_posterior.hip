@@ -329,13 +329,11 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
     double acc[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[j] = 0.0;
-    bool first_round = true;
+    int4 rr_cur = rrf;                                                           // the records of the round about to run
     for (int base = qb; __builtin_amdgcn_ballot_w64(base < qe) != 0; base += RCG) {
         const int q = base + col;
         const bool act = q < qe;
-        int4 rr = rrf;
-        if (!first_round) rr = nt_load(&A.rowrec[act ? q : qb]);
-        first_round = false;
+        const int4 rr = rr_cur;
         const double2 *Cc = A.C + rr.x;
         const int ne = act ? (rr.z >> 8) : 0;
         const int tb = rr.y;
@@ -347,6 +345,10 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
             const int e = sub + u * kSub;
             pv[u] = (int)__builtin_nontemporal_load(&A.tp[tb + (e < ne ? e : 0)]);
             br[u] = Cc[1 + (e < ne ? e : 0)];
+        }
+        {   // the next round's records with this round's gathers (post_column)
+            const int nb = base + RCG;
+            rr_cur = nt_load(&A.rowrec[(nb + col < qe) ? nb + col : qb]);
         }
         const double Bk = act ? own.x : 0.0, Rk = (act && ne > 0) ? own.y : 0.0;
         if (__builtin_amdgcn_ballot_w64(ne > 0) == 0) continue;                 // only the columns themselves in this round
@@ -386,6 +388,7 @@ __global__ void __launch_bounds__(256) gpv_posterior_level_group_kernel(const Po
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::"v"(rr_cur.x), "v"(rr_cur.y), "v"(rr_cur.z), "v"(rr_cur.w));      // (see post_column)
     }
     // row r of the sums sits in lane r % LPC (of the group), register r / LPC
     auto row_value = [&](const int r) -> double {
