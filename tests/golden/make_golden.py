@@ -22,7 +22,17 @@ def case(name, locs, z, m, ordering, cond, covmodel, covparms, nuggets):
     U = R.createU(va, covparms, nuggets, covmodel)
     ll = R.vecchia_likelihood_U(z, U)
     prep = va["U_prep"]
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), locs=locs, z=z, m=m, ordering=ordering, cond=cond,
+    # the posterior quantities (row f-1 of SURVEY.md section 8: U2V, the denominator terms, vecchia_mean) of the same case
+    V = R.U2V(U)                                                                   # R/vecchia_prediction.R:62-111
+    mu_obs = R.vecchia_mean(z, U, V)                                               # :118-142
+    lat = U["latent"]
+    zord = np.asarray(z)[U["ord_z"] - 1]
+    z1 = U["U"][~lat, :].T @ zord
+    z2 = U["U"][lat, :] @ z1
+    z3 = np.linalg.solve(V, z2[::-1])                                              # R/vecchia_likelihood.R:88 (V lower triangular)
+    post = dict(mu_obs=mu_obs, logdet_denom=-2 * np.sum(np.log(np.diag(V))), quadform_denom=np.sum(z3 ** 2),
+                V_diag=np.diag(V).copy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), locs=locs, z=z, m=m, ordering=ordering, cond=cond, **post,
                         covmodel=covmodel, covparms=np.asarray(covparms, float), nuggets=np.asarray(nuggets, float),
                         ord=va["ord"], revNNarray=np.nan_to_num(prep["revNNarray"]).astype(np.int32),
                         revCond=np.nan_to_num(prep["revCond"], nan=-1).astype(np.int8),

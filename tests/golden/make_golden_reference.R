@@ -2,7 +2,8 @@
 # tests/golden/make_golden_reference.R -- closes the parity pin: runs the REAL GPvecchia package (the unmodified
 # reference: install.packages("GPvecchia"), or R CMD INSTALL of a checkout of katzfuss-group/GPvecchia) on the committed
 # raw inputs tests/golden/raw/<case>/ (written by tests/golden/export_raw_inputs.py) and dumps, per case,
-#   tests/golden/reference_run/<case>/{Lentries.f64, Zentries.f64, loglik.f64, U_i.i32, U_j.i32, U_x.f64, specify.txt}
+#   tests/golden/reference_run/<case>/{Lentries.f64, Zentries.f64, loglik.f64, U_i.i32, U_j.i32, U_x.f64, mu_obs.f64, V_diag.f64,
+#   specify.txt}
 # in the layout tests/test_reference_run.py reads.
 #
 # THIS SCRIPT HAS NOT BEEN RUN in the repository that ships it: neither its build image nor its GPU box has R, and the
@@ -19,6 +20,7 @@
 #                         ordering / neighbour search cannot blur the comparison of the hot path;
 #   U (i, j, x)         : createU()$U (R/createU.R:156-199) as triplets;
 #   loglik              : vecchia_likelihood() (R/vecchia_likelihood.R:14-27);
+#   mu_obs, V_diag      : vecchia_mean() on U2V() of the same U.obj (R/vecchia_prediction.R:62-142): the posterior pass;
 #   specify.txt         : whether the package's OWN vecchia_specify() reproduces the fixture's ord / NNarray / Cond.
 suppressPackageStartupMessages({ library(GPvecchia); library(Matrix) })
 
@@ -65,6 +67,10 @@ for (case in list.dirs(file.path(gold, "raw"), full.names = FALSE, recursive = F
   U <- createU(va, covparms, nuggets, covmodel)$U
   ll <- vecchia_likelihood(z, va, covparms, nuggets, covmodel)
   trip <- summary(as(U, "generalMatrix"))
+  # the posterior quantities (row f-1): U2V, the denominator terms of vecchia_likelihood_U, vecchia_mean
+  U.obj <- createU(va, covparms, nuggets, covmodel)
+  V.ord <- GPvecchia:::U2V(U.obj)                                         # R/vecchia_prediction.R:62-111
+  mu.obs <- GPvecchia:::vecchia_mean(z, U.obj, V.ord)$mu.obs              # :118-142
 
   out <- file.path(gold, "reference_run", case)
   dir.create(out, recursive = TRUE, showWarnings = FALSE)
@@ -73,6 +79,8 @@ for (case in list.dirs(file.path(gold, "raw"), full.names = FALSE, recursive = F
   wr(as.double(ll), file.path(out, "loglik.f64"))
   wr(as.integer(trip$i), file.path(out, "U_i.i32")); wr(as.integer(trip$j), file.path(out, "U_j.i32"))
   wr(as.double(trip$x), file.path(out, "U_x.f64"))
+  wr(as.double(mu.obs), file.path(out, "mu_obs.f64"))
+  wr(as.double(Matrix::diag(V.ord)), file.path(out, "V_diag.f64"))        # logdet.denom = -2 sum(log(.)), R/vecchia_likelihood.R:90
   writeLines(c(paste0("GPvecchia=", as.character(packageVersion("GPvecchia"))), paste0("R=", R.version.string),
                paste0("RcppArmadillo=", as.character(packageVersion("RcppArmadillo"))),
                paste0("own_specify_reproduces_", names(own), "=", own), paste0("n.cores=", va$U.prep$n.cores),

@@ -33,6 +33,17 @@ def test_oracle_reproduces_golden(path):
     U = R.createU(va, g["covparms"], nug, str(g["covmodel"]))
     np.testing.assert_allclose(U["U_entries"]["Lentries"], g["Lentries"], rtol=0, atol=1e-12 * np.abs(g["Lentries"]).max())
     assert abs(R.vecchia_likelihood_U(g["z"], U) - float(g["loglik"])) <= 1e-11 * abs(float(g["loglik"]))
+    # the posterior quantities (U2V, denominator terms, vecchia_mean), from the dense restatement and from the sparse one
+    V = R.U2V(U)
+    np.testing.assert_allclose(np.diag(V), g["V_diag"], rtol=1e-11)
+    np.testing.assert_allclose(R.vecchia_mean(g["z"], U, V), g["mu_obs"], rtol=0, atol=1e-11 * np.abs(g["mu_obs"]).max())
+    Us = R.createU_sparse(va, g["covparms"], nug, str(g["covmodel"]))
+    ll_s, t = R.vecchia_likelihood_U_sparse(g["z"], Us, terms=True)
+    assert abs(ll_s - float(g["loglik"])) <= 1e-11 * abs(float(g["loglik"]))
+    assert abs(t["logdet_denom"] - float(g["logdet_denom"])) <= 1e-11 * max(abs(float(g["logdet_denom"])), 1.0)
+    assert abs(t["quadform_denom"] - float(g["quadform_denom"])) <= 1e-10 * max(abs(float(g["quadform_denom"])), 1.0)
+    np.testing.assert_allclose(R.vecchia_mean_sparse(g["z"], Us, t["V"]), g["mu_obs"], rtol=0,
+                               atol=1e-11 * np.abs(g["mu_obs"]).max())
 
 
 @pytest.mark.gpu
@@ -54,3 +65,12 @@ def test_hip_path_matches_golden(path):
     np.testing.assert_allclose(U["Zentries"], g["Zentries"], rtol=1e-15)
     ll = G.vecchia_likelihood(g["z"], va, g["covparms"], nug, str(g["covmodel"]))
     assert abs(ll - float(g["loglik"])) <= 1e-8 * abs(float(g["loglik"]))
+    # posterior mean (vecchia_prediction) and, where the posterior pass ran on the device, its two sums
+    mu = G.vecchia_prediction(g["z"], va, g["covparms"], nug, str(g["covmodel"]))["mu_obs"]
+    np.testing.assert_allclose(mu, g["mu_obs"], rtol=0, atol=1e-8 * np.abs(g["mu_obs"]).max())
+    plan = va.get(("_plan", 0))
+    if str(g["cond"]) == "SGV" and plan is not None and plan.has_posterior:
+        G.vecchia_likelihood(g["z"], va, g["covparms"], nug, str(g["covmodel"]))          # (the sums of a GPV_WANT_DENOM evaluation)
+        s = plan.sums()
+        assert abs(-s[2] - float(g["logdet_denom"])) <= 1e-8 * max(abs(float(g["logdet_denom"])), 1.0)
+        assert abs(s[3] - float(g["quadform_denom"])) <= 1e-8 * max(abs(float(g["quadform_denom"])), 1.0)

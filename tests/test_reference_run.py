@@ -42,7 +42,12 @@ def _ref(case):
                            Zentries=np.fromfile(os.path.join(d, "Zentries.f64"), "<f8"),
                            loglik=float(np.fromfile(os.path.join(d, "loglik.f64"), "<f8")[0]),
                            U=(np.fromfile(os.path.join(d, "U_i.i32"), "<i4"), np.fromfile(os.path.join(d, "U_j.i32"), "<i4"),
-                              np.fromfile(os.path.join(d, "U_x.f64"), "<f8")))
+                              np.fromfile(os.path.join(d, "U_x.f64"), "<f8")),
+                           # the posterior pass (written by the script since round 5; absent in an older reference run)
+                           mu_obs=(np.fromfile(os.path.join(d, "mu_obs.f64"), "<f8")
+                                   if os.path.exists(os.path.join(d, "mu_obs.f64")) else None),
+                           V_diag=(np.fromfile(os.path.join(d, "V_diag.f64"), "<f8")
+                                   if os.path.exists(os.path.join(d, "V_diag.f64")) else None))
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -97,6 +102,10 @@ def test_oracle_matches_reference_run(case):
     i, j, x = ref["U"]
     dense = np.zeros_like(U["U"]); dense[i - 1, j - 1] = x
     np.testing.assert_allclose(U["U"], dense, rtol=0, atol=1e-8 * np.abs(x).max())
+    if ref["mu_obs"] is not None:
+        V = R.U2V(U)
+        np.testing.assert_allclose(np.diag(V), ref["V_diag"], rtol=1e-8)
+        np.testing.assert_allclose(R.vecchia_mean(raw["z"], U, V), ref["mu_obs"], rtol=0, atol=1e-8 * np.abs(ref["mu_obs"]).max())
 
 
 @pytest.mark.gpu
@@ -115,3 +124,6 @@ def test_hip_path_matches_reference_run(case):
     np.testing.assert_allclose(U["Zentries"], ref["Zentries"], rtol=1e-15)
     ll = G.vecchia_likelihood(raw["z"], va, raw["covparms"], nug, meta["covmodel"])
     assert abs(ll - ref["loglik"]) <= 1e-8 * abs(ref["loglik"])
+    if ref["mu_obs"] is not None:
+        mu = G.vecchia_prediction(raw["z"], va, raw["covparms"], nug, meta["covmodel"])["mu_obs"]
+        np.testing.assert_allclose(mu, ref["mu_obs"], rtol=0, atol=1e-8 * np.abs(ref["mu_obs"]).max())
