@@ -800,10 +800,29 @@ def main():
                     ts = time.time() - t0
                     el, km, ll = measure(ps, G.GPV_WANT_DENOM, True, args.steps, 2)
                     sums_S, mu_S = ps.sums().copy(), None
+                    pass_roof = None
+                    try:
+                        # the posterior pass against ITS roofline: L2 line misses (a scattered 16-byte gather moves one 128-byte
+                        # line; the chip serves ~54 such lines per ns: tools/ubench/gather_lines.hip) per
+                        # nanosecond of pass.  Misses: the per-level counters of this workload under profiles/ (PMC passes cannot
+                        # run inside a timed bench); pass time: this run's evaluation minus its set kernel.
+                        lv = json.load(open(os.path.join(ROOT, "profiles", "r05_posterior_levels_pmc.json")))
+                        misses = sum(v.get("TCC_MISS_sum", 0.0) for v in lv.values())
+                        pass_ms = 1e3 * el / args.steps - km
+                        pass_roof = {"bound": "l2_miss_lines", "pass_ms": pass_ms, "l2_line_misses": misses,
+                                     "achieved": misses / (pass_ms * 1e6), "peak": 54.0, "unit": "128-byte lines/ns",
+                                     "frac": misses / (pass_ms * 1e6) / 54.0,
+                                     "note": "pass_ms = evaluation - set kernel (includes the dense top block, the two "
+                                             "reduction kernels and the launch floor of ~45 narrow levels); misses from "
+                                             "profiles/r05_posterior_levels_pmc.json (same workload)"}
+                    except Exception:
+                        pass_roof = None
                     sec["mode_S"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
                                      "sets_kernel_ms": km, "loglik": ll, "levels": nlev, "setup_s": round(ts, 2),
                                      "what": "the reference's defaults: ordering='maxmin', cond.yz='SGV'; set kernel + "
                                              "posterior pass (U2V) on one GPU; does not shard"}
+                    if pass_roof is not None and args.config == "C3" and not custom:      # (the counters are this workload's)
+                        sec["mode_S"]["pass_roofline"] = pass_roof
                     # the same evaluation with the posterior mean (R/vecchia_prediction.R:118-126: one more level-scheduled
                     # sweep R^T u = t; what every Newton step of the Vecchia-Laplace loop runs)
                     try:
