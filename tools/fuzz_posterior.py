@@ -1,7 +1,8 @@
 """Developer tool: the posterior pass (factor, denominator, posterior mean) on random plan shapes against the host route
-(createU + SuperLU), one-off sweeps on a GPU box.  Sizes straddle the dense top block's limits (64, 128 columns).
+(createU + SuperLU) and, with --oracle, against the oracle's sparse restatement of the R chain (oracle/r_side.py) as well;
+one-off sweeps on a GPU box.  Sizes straddle the dense top block's limits (64, 128 columns).
 
-    python tools/fuzz_posterior.py [first_seed last_seed]
+    python tools/fuzz_posterior.py [first_seed last_seed] [--oracle]
 """
 import os
 import sys
@@ -13,7 +14,13 @@ import torch  # noqa: F401  (one HIP runtime per process)
 import gpvecchia_amd as G
 from gpvecchia_amd import api as A
 
-lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 150)
+ORACLE = "--oracle" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--oracle"]
+lo, hi = (int(argv[0]), int(argv[1])) if len(argv) > 1 else (0, 150)
+if ORACLE:
+    sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+    from oracle import r_side as R
+    from test_gpu_fuzz import _oracle_va
 bad = 0
 worst = 0.0
 for seed in range(lo, hi):
@@ -37,6 +44,13 @@ for seed in range(lo, hi):
         sc = max(np.abs(mo_h).max(), 1e-300)
         e1 = abs(ll - ll_h) / max(abs(ll_h), 1.0)
         e2 = np.abs(pred["mu_obs"] - mo_h).max() / sc
+        if ORACLE:
+            Us = R.createU_sparse(_oracle_va(va), cp, tau)
+            V = R.U2V_sparse(Us)
+            ll_o = R.vecchia_likelihood_U_sparse(z, Us, V=V)
+            mo_o = R.vecchia_mean_sparse(z, Us, V)
+            e1 = max(e1, abs(ll - ll_o) / max(abs(ll_o), 1.0))
+            e2 = max(e2, np.abs(pred["mu_obs"] - mo_o).max() / max(np.abs(mo_o).max(), 1e-300))
         worst = max(worst, e1, e2)
         plan = va.get(("_plan", 0))
         route = pred.get("route")
