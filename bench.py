@@ -75,18 +75,44 @@ def build_workload(n, m, d, rank, world, seed=0, device=0):
     return locs, z, revNN, revCond, a, b
 
 
-def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, keep=None):
-    """Time the oracle's C restatement of U_NZentries (OpenMP, all host cores) on the conditioning sets
-    [a, b) of the SAME workload (the whole data set when it fits the time budget).  keep: a dict that receives the
-    oracle's U entries of those sets (`Lentries`, rows a..b-1) for the parity_in_run block — the checker's output is
-    compared with the GPU's, never fed back into it."""
+def host_cpu_topology():
+    """(logical CPUs this process may run on, physical cores among them) from the affinity mask and /proc/cpuinfo
+    (distinct (physical id, core id) pairs); physical = logical where the file does not say."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    cores = set()
+    try:
+        cpu, phys, core = None, None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("processor"):
+                cpu, phys, core = int(line.split(":")[1]), None, None
+            elif line.startswith("physical id"):
+                phys = int(line.split(":")[1])
+            elif line.startswith("core id"):
+                core = int(line.split(":")[1])
+                if cpu in allowed and phys is not None:
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    logical = len(allowed)
+    physical = len(cores) if 0 < len(cores) <= logical else logical
+    return logical, physical
+
+
+def marshal_cpu_sample(locs, revNN, revCond, covparms, tau, rows_sample):
+    """The oracle's arguments for the conditioning sets [a, b) of the workload, in the C function's own layout, built ONCE
+    outside every timer (oracle.r_side.marshal_U_NZentries: Fortran-order float64 / int64 arrays, outputs allocated and
+    touched).  Returns (marshalled arguments, seconds the marshalling took, whether it is the whole data set)."""
     from oracle import r_side as R
+    t0 = time.perf_counter()
     a, b = rows_sample
     n = locs.shape[0]
     full = (a == 0 and b == n)
     if full:
         lp, nnp = locs, revNN
-        cdp = np.where(revCond < 0, 0, revCond).astype(np.float64)
+        cdp = np.where(revCond < 0, 0, revCond)
         Nl = n
     else:
         sub = revNN[a:b]
@@ -101,28 +127,72 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, ke
         lp = np.zeros((Nl, locs.shape[1]))
         lp[: used.size] = locs[used]
     nug = np.full(Nl, tau)
-    cores = R.max_threads()
+    ms = R.marshal_U_NZentries(1, lp, nnp, cdp, nug, nug[:1], "matern", covparms)
+    return ms, time.perf_counter() - t0, full
+
+
+def time_oracle_function(ms, threads, repeats, probe=None):
+    """Seconds of `repeats` calls of the C function oracle_U_NZentries ALONE ("wall-clock of the function
+    only"): the ctypes function object on pre-marshalled arguments, nothing else between the two clock reads.  `probe`
+    (tests) receives the callable that is timed."""
+    fn, cargs = ms.fn, ms.cargs(threads)
+    if probe is not None:
+        probe(fn)
     times = []
     for _ in range(repeats):
         t0 = time.perf_counter()
-        ref = R.U_NZentries(cores, 1, lp, nnp, cdp, nug, nug[:1], "matern", covparms)
+        nf = fn(*cargs)
         times.append(time.perf_counter() - t0)
+    return times, int(nf)
+
+
+def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, keep=None, sweep=True, probe=None):
+    """Time the oracle's C restatement of U_NZentries (src/U_NZentries.cpp:37-69; OpenMP schedule(static)) on the
+    conditioning sets [a, b) of the SAME workload (the whole data set when it fits the time budget).  The arguments are
+    marshalled once, outside the timer; the timed callable is the C function.  `value` is quoted on all logical CPUs (the
+    reference's own choice: Ncores = detectCores(logical=TRUE), R/U_sparsity.R:76); `thread_sweep` repeats the function on
+    {1, physical cores, all logical CPUs} (1 thread: on a bounded row sample).  keep: a dict that receives the oracle's U
+    entries of those sets (`Lentries`, rows a..b-1) for the parity_in_run block — the checker's output is compared with
+    the GPU's, never fed back into it."""
+    a, b = rows_sample
+    n = locs.shape[0]
+    logical, physical = host_cpu_topology()
+    ms, marshal_s, full = marshal_cpu_sample(locs, revNN, revCond, covparms, tau, rows_sample)
+    times, nfail = time_oracle_function(ms, logical, repeats, probe)
     if keep is not None:
-        keep["Lentries"] = ref["Lentries"][: b - a]
-        keep["n_failed"] = ref["n_failed"]
+        keep["Lentries"] = ms.L[: b - a]
+        keep["n_failed"] = nfail
         keep["rows"] = (a, b)
-    del ref
     t = float(np.median(times))
     sets_per_s = (b - a) / t
+    sw = [{"threads": logical, "rows": b - a, "seconds": t, "sets_per_s": sets_per_s}]
+    if sweep:
+        if physical != logical:
+            tp, _ = time_oracle_function(ms, physical, repeats, probe)
+            tp = float(np.median(tp))
+            sw.append({"threads": physical, "rows": b - a, "seconds": tp, "sets_per_s": (b - a) / tp})
+        # one thread: a bounded row sample (full rows, n0 = m + 1) — the whole data set would take ~20 s per repeat
+        r1 = min(b - a, 60000)
+        if r1 == b - a:
+            m1 = ms
+        else:
+            m1, _, _ = marshal_cpu_sample(locs, revNN, revCond, covparms, tau, (b - r1, b))
+        t1, _ = time_oracle_function(m1, 1, 2, probe)
+        t1 = float(np.median(t1))
+        sw.append({"threads": 1, "rows": r1, "seconds": t1, "sets_per_s": r1 / t1})
+        sw.sort(key=lambda e: e["threads"])
+    what = ("oracle/u_nzentries_oracle.c oracle_U_NZentries, the C function ALONE on pre-marshalled arguments (ctypes call "
+            f"between two clock reads; marshalling {marshal_s:.2f} s reported apart as marshal_s)")
     if full:
-        sample = (f"all {n} conditioning sets (no extrapolation), oracle/u_nzentries_oracle.c U_NZentries only, OpenMP "
-                  f"schedule(static) on {cores} threads, median of {repeats} = {t:.3f} s")
+        sample = (f"all {n} conditioning sets (no extrapolation), {what}, OpenMP schedule(static) on {logical} threads "
+                  f"(all logical CPUs of {physical} physical cores), median of {repeats} = {t:.3f} s")
     else:
-        sample = (f"{b - a} of {n} conditioning sets (rows {a}..{b - 1}, all with n0=m+1), oracle/u_nzentries_oracle.c "
-                  f"U_NZentries only, OpenMP schedule(static) on {cores} threads, median of {repeats} = {t:.3f} s, "
+        sample = (f"{b - a} of {n} conditioning sets (rows {a}..{b - 1}, all with n0=m+1), {what}, OpenMP schedule(static) on "
+                  f"{logical} threads (all logical CPUs of {physical} physical cores), median of {repeats} = {t:.3f} s, "
                   f"EXTRAPOLATED linearly to n")
-    return dict(value=sets_per_s / n, unit="evals/s", cores=cores, kind="port", sample=sample,
-                extrapolated=not full, sets_per_s=sets_per_s, seconds=t,
+    return dict(value=sets_per_s / n, unit="evals/s", cores=logical, physical_cores=physical, kind="port", sample=sample,
+                extrapolated=not full, sets_per_s=sets_per_s, seconds=t, marshal_s=marshal_s, thread_sweep=sw,
+                timed_callable="ctypes oracle_U_NZentries",
                 note="own C restatement of src/U_NZentries.cpp:39-69 without Armadillo's per-iteration temporaries: "
                      "FASTER than the real reference (BASELINE.md §2), which cannot be built on this box")
 
@@ -881,7 +951,7 @@ def main():
                     sec["per_rank_step"] = {"error": repr(e)}
             out["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline and args.mode != "S":
-            cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - min(b - a - 2 * p, 60000), b), repeats=2)
+            cal = cpu_baseline(locs, revNN, revCond, covparms, tau, (b - min(b - a - 2 * p, 60000), b), repeats=2, sweep=False)
             kept = {}
             if n / cal["sets_per_s"] <= args.cpu_budget_s:
                 out["cpu_baseline"] = cpu_baseline(locs, revNN, revCond, covparms, tau, (0, n), repeats=3, keep=kept)

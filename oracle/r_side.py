@@ -84,31 +84,59 @@ def max_threads() -> int:
     return int(_lib().oracle_max_threads())
 
 
+class MarshalledSets:
+    """The arguments of oracle_U_NZentries in the C function's own layout (what Rcpp's converters produce before
+    src/U_NZentries.cpp:25 starts: src/RcppExports.cpp:57-63), with caller-allocated, pre-touched outputs.  `cargs(Ncores)` is
+    the exact ctypes argument tuple; `fn` is the ctypes function object itself."""
+
+    def __init__(self, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covType, covparms):
+        self.locs = np.asfortranarray(locs, dtype=np.float64)
+        self.Nlocs, self.d = self.locs.shape
+        nn = np.asarray(revNNarray)
+        if nn.dtype.kind == "f":
+            nn = np.nan_to_num(nn, nan=0.0)
+        self.nn = np.asfortranarray(nn.astype(np.int64))
+        self.p = self.nn.shape[1]
+        cd = np.asarray(revCondOnLatent)
+        if cd.dtype.kind == "f":
+            cd = np.nan_to_num(cd, nan=0.0)
+        self.cond = np.asfortranarray(cd, dtype=np.float64)
+        self.nug = np.ascontiguousarray(nuggets, dtype=np.float64)
+        self.nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)
+        self.cp = np.ascontiguousarray(covparms, dtype=np.float64)
+        self.n = int(n)
+        self.code = {"matern": 0, "esqe": 1}.get(covType, 99)
+        self.closed_form = not (self.code == 0 and float(self.cp[2]) not in (0.5, 1.5, 2.5))
+        self.L = np.zeros((self.Nlocs, self.p), dtype=np.float64, order="F")      # zeros(): pages touched here, not in the call
+        self.Z = np.zeros(2 * self.n, dtype=np.float64)
+        self.L[...] = 0.0
+        self.fn = _lib().oracle_U_NZentries
+
+    def cargs(self, Ncores):
+        return (int(Ncores), self.n, int(self.Nlocs), int(self.d), int(self.p), _dptr(self.locs),
+                self.nn.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), _dptr(self.cond), _dptr(self.nug), _dptr(self.nugo),
+                self.code, _dptr(self.cp), _dptr(self.L), _dptr(self.Z))
+
+
+def marshal_U_NZentries(n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covType, covparms):
+    """Everything U_NZentries() below does BEFORE the C function is entered, once: bench.py's cpu_baseline times
+    `m.fn(*m.cargs(threads))` — the function only — and reports this step separately."""
+    return MarshalledSets(n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covType, covparms)
+
+
 def U_NZentries(Ncores, n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covType, covparms):
     """R/RcppExports.R:22-24 -> src/U_NZentries.cpp:25-118 (through the C restatement).
 
     revNNarray: (Nlocs, p) 1-based with 0 for missing (R/createU.R:146-147).
     Returns dict(Lentries=(Nlocs,p), Zentries=(2n,), n_failed)."""
-    locs = np.asfortranarray(locs, dtype=np.float64)
-    Nlocs, d = locs.shape
-    nn = np.asfortranarray(np.nan_to_num(np.asarray(revNNarray, dtype=np.float64), nan=0.0).astype(np.int64))
-    p = nn.shape[1]
-    cond = np.asfortranarray(np.nan_to_num(np.asarray(revCondOnLatent, dtype=np.float64), nan=0.0))
-    nug = np.ascontiguousarray(nuggets, dtype=np.float64)
-    nugo = np.ascontiguousarray(nuggets_obsord, dtype=np.float64)
-    cp = np.ascontiguousarray(covparms, dtype=np.float64)
-    code = {"matern": 0, "esqe": 1}.get(covType, 99)
-    if code == 0 and float(cp[2]) not in (0.5, 1.5, 2.5):
+    m = MarshalledSets(n, locs, revNNarray, revCondOnLatent, nuggets, nuggets_obsord, covType, covparms)
+    if not m.closed_form:
         # Bessel branch (src/Matern.cpp:72-84): the C restatement has no K_nu, use the numpy one
-        return U_NZentries_numpy(n, locs, nn, cond, nug, nugo, cp)
-    L = np.zeros((Nlocs, p), dtype=np.float64, order="F")
-    Z = np.zeros(2 * int(n), dtype=np.float64)
-    nf = _lib().oracle_U_NZentries(int(Ncores), int(n), int(Nlocs), int(d), int(p), _dptr(locs),
-                                   nn.ctypes.data_as(ctypes.POINTER(ctypes.c_long)), _dptr(cond), _dptr(nug),
-                                   _dptr(nugo), code, _dptr(cp), _dptr(L), _dptr(Z))
+        return U_NZentries_numpy(n, m.locs, m.nn, m.cond, m.nug, m.nugo, m.cp)
+    nf = m.fn(*m.cargs(Ncores))
     if nf < 0:
         raise ValueError(f"{covType} covariance is not implemented")      # src/U_NZentries.cpp:27-29
-    return dict(Lentries=np.array(L), Zentries=Z, n_failed=int(nf))
+    return dict(Lentries=m.L, Zentries=m.Z, n_failed=int(nf))
 
 
 def rows_extended(rows, locs, revNNarray, revCondOnLatent, nuggets, covType, covparms, covVals=None):
