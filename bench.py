@@ -353,7 +353,30 @@ def other_config(name, device, measure_with, steps=10, b2b=None):
             "what": f"BASELINE.json configs[{ci}]: n={n} {d}-D, m={m}, Matern nu={nu}, range {rng_}, cond.yz='z', mode L, 1 GPU"}
 
 
-def vl_config(device, n=500_000, m=30):
+def vl_oracle(z, va, cp, post, ll):
+    """Parity evidence for secondary.C5_vl (outside every timed region): the Newton LOOP of R/vecchia_laplace_NR.R:88-130 and
+    vecchia_laplace_likelihood (:361-416) restated by the oracle on sparse matrices (oracle.r_side.calculate_posterior_VL_sparse:
+    createU_sparse -> U2V_sparse -> vecchia_mean_sparse per step), on the same data and plan, against what the GPU returned."""
+    from oracle import r_side as R
+    t0 = time.time()
+    prep = dict(va["U_prep"])
+    nn = prep["revNNarray"]
+    prep["revNNarray"] = np.where(nn == 0, np.nan, nn.astype(np.float64))
+    prep["revCond"] = np.where(prep["revCond"] < 0, np.nan, prep["revCond"].astype(np.float64))
+    ova = {k: v for k, v in va.items() if not isinstance(k, tuple)}
+    ova["U_prep"] = prep
+    tr = []
+    ref = R.calculate_posterior_VL_sparse(z, ova, "poisson", cp, trace=tr, snapshot_convg=1e-5)
+    ll_ref = R.vecchia_laplace_likelihood_sparse(z, ova, "poisson", cp, post=ref["snapshot"])
+    return {"iters_hip": int(post["iter"]), "iters_oracle": int(ref["iter"]), "converged_oracle": bool(ref["cnvgd"]),
+            "mean_max_abs_err": float(np.abs(post["mean"] - ref["mean"]).max()), "mean_abs_max": float(np.abs(ref["mean"]).max()),
+            "loglik_oracle": float(ll_ref), "loglik_rel_err": float(abs(ll - ll_ref) / abs(ll_ref)),
+            "oracle_newton_trace": tr, "oracle_s": round(time.time() - t0, 1),
+            "what": "G.calculate_posterior_VL / G.vecchia_laplace_likelihood (device Newton loop) vs "
+                    "oracle.r_side.{calculate_posterior_VL_sparse,vecchia_laplace_likelihood_sparse} on the same z and plan"}
+
+
+def vl_config(device, n=500_000, m=30, parity=True):
     """BASELINE.json configs[4]: Vecchia-Laplace, Poisson data, maxmin + SGV, one GPU (the posterior pass does not shard)."""
     import gpvecchia_amd as G
     rng = np.random.default_rng(0)
@@ -378,7 +401,14 @@ def vl_config(device, n=500_000, m=30):
         t0 = time.time()
         ll = G.vecchia_laplace_likelihood(z, va, "poisson", cp, device=device)
         t_ll.append(time.time() - t0)
-    return {"ms_per_nr_iter": 1e3 * t_nr / max(post["iter"], 1), "nr_iters": int(post["iter"]), "converged": bool(post["cnvgd"]),
+    par = None
+    if parity:
+        try:
+            par = vl_oracle(z, va, cp, post, ll)
+        except Exception as e:                                # noqa: BLE001
+            par = {"error": repr(e)}
+    return {"parity_in_run": par,
+            "ms_per_nr_iter": 1e3 * t_nr / max(post["iter"], 1), "nr_iters": int(post["iter"]), "converged": bool(post["cnvgd"]),
             "nr_loop_s": t_nr, "vecchia_laplace_likelihood_s": float(np.median(t_ll)), "loglik": ll,
             "rmse_latent": float(np.sqrt(np.mean((post["mean"] - y) ** 2))), "specify_s": round(t_spec, 2),
             "first_call_s": round(t_first, 2),
@@ -474,6 +504,8 @@ def main():
     ap.add_argument("--nu", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the mode U / mode S secondary measurements")
+    ap.add_argument("--no-vl-parity", action="store_true",
+                    help="skip secondary.C5_vl.parity_in_run (the oracle's sparse Vecchia-Laplace loop at n = 5e5: ~1.5 min of host time)")
     ap.add_argument("--cpu-budget-s", type=float, default=10.0,
                     help="per-repeat wall budget of the CPU baseline; the whole data set is timed when it fits")
     ap.add_argument("--clock-warmup-s", type=float, default=0.1,
@@ -938,7 +970,7 @@ def main():
                     except Exception as e:
                         sec[name] = {"error": repr(e)}
                 try:
-                    sec["C5_vl"] = vl_config(local_rank)
+                    sec["C5_vl"] = vl_config(local_rank, parity=not (args.no_cpu_baseline or args.no_vl_parity))
                 except Exception as e:
                     sec["C5_vl"] = {"error": repr(e)}
                 try:

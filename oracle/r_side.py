@@ -1065,6 +1065,20 @@ def vecchia_mean_sparse(z, U_obj, V, both=False, ordered=False):
     return mu[obs_orig]
 
 
+def vecchia_prediction_mean_sparse(z, va, covparms, nuggets, covmodel="matern", both=False):
+    """vecchia_prediction_mean above on sparse matrices (R/vecchia_prediction.R:17-56, return.values='meanmat')."""
+    z, nuggets = removeNAs(z, nuggets)                                 # :22
+    U_obj = createU_sparse(va, covparms, nuggets, covmodel)            # :25
+    V = U2V_sparse(U_obj)                                              # :28
+    return vecchia_mean_sparse(z, U_obj, V, both)                      # :34
+
+
+def vecchia_likelihood_sparse(z, va, covparms, nuggets, covmodel="matern"):
+    """vecchia_likelihood above on sparse matrices (R/vecchia_likelihood.R:14-27)."""
+    z, nuggets = removeNAs(z, nuggets)                                 # :20
+    return vecchia_likelihood_U_sparse(z, createU_sparse(va, covparms, nuggets, covmodel))
+
+
 def posterior_extended(z, va, covparms, nuggets, covmodel="matern"):
     """The adjudicator for the posterior pass: the chain createU -> U2V -> vecchia_likelihood_U / vecchia_mean
     (R/createU.R:141-171, R/vecchia_prediction.R:62-83,118-126, R/vecchia_likelihood.R:63-99; general ordering, positive
@@ -1129,8 +1143,13 @@ def vl_family(model, likparms=None):
 
 
 def calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel="matern", likparms=None, max_iter=50,
-                           convg=1e-6, prior_mean=None):
-    """R/vecchia_laplace_NR.R:31-155, missing observations (NaN in z) included."""
+                           convg=1e-6, prior_mean=None, sparse=False, trace=None, snapshot_convg=None):
+    """R/vecchia_laplace_NR.R:31-155, missing observations (NaN in z) included.  sparse=True: every step's
+    vecchia_prediction on sparse matrices (vecchia_prediction_mean_sparse: what the reference does, feasible at n = 5e5);
+    trace: a list that receives max|y_o - y_prev| of every step (:124); snapshot_convg: a looser threshold — the result
+    carries under "snapshot" the posterior the SAME loop would have returned with convg = snapshot_convg (the iterations
+    are a prefix of these: vecchia_laplace_likelihood's default 1e-5 against 1e-6 here, without running the loop twice)."""
+    predict = vecchia_prediction_mean_sparse if sparse else vecchia_prediction_mean
     z = np.asarray(z, dtype=np.float64)
     fam = vl_family(likelihood_model, likparms)
     pm = np.zeros(len(z)) if prior_mean is None else np.asarray(prior_mean, float)
@@ -1140,6 +1159,7 @@ def calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel="matern",
     if len(y_o) > 1:
         y_o = y_o[obs]                                                 # :84
     convgd, tot = False, 0
+    snap = None
     for i in range(1, max_iter + 1):                                   # :88
         y_prev = y_o
         D = 1 / fam["hess"](y_o, z_obs)                                # :93,100
@@ -1148,20 +1168,33 @@ def calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel="matern",
         pseudo[obs] = D * u + y_o - pm[obs]                            # :105
         nuggets = np.full(len(z), np.inf)                              # :107
         nuggets[obs] = D                                               # :108
-        mu = vecchia_prediction_mean(pseudo, va, covparms, nuggets, covmodel)    # :112-113
+        mu = predict(pseudo, va, covparms, nuggets, covmodel)          # :112-113
         y_o = mu[obs] + pm[obs]                                        # :115
+        if trace is not None:
+            trace.append(float(np.max(np.abs(y_o - y_prev))))
+        if snapshot_convg is not None and snap is None and np.max(np.abs(y_o - y_prev)) < snapshot_convg:
+            snap = dict(mean=mu + pm, cnvgd=True, iter=i, t=pseudo + pm, D=D, model_llh=fam["llh"], prior_mean=pm)
         if np.max(np.abs(y_o - y_prev)) < convg:                       # :124
             convgd, tot = True, i
             break
         tot += 1
-    return dict(mean=mu + pm, cnvgd=convgd, iter=tot, t=pseudo + pm, D=D, model_llh=fam["llh"], prior_mean=pm)
+    out = dict(mean=mu + pm, cnvgd=convgd, iter=tot, t=pseudo + pm, D=D, model_llh=fam["llh"], prior_mean=pm)
+    if snapshot_convg is not None:
+        out["snapshot"] = snap
+    return out
 
 
 def vecchia_laplace_likelihood(z, va, likelihood_model, covparms, likparms=None, covmodel="matern", max_iter=50,
-                               convg=1e-5, prior_mean=None):
-    """R/vecchia_laplace_NR.R:361-416."""
+                               convg=1e-5, prior_mean=None, sparse=False, post_out=None, post=None):
+    """R/vecchia_laplace_NR.R:361-416.  sparse=True: the loop and the pseudo-marginal likelihood on sparse matrices;
+    post_out: a dict that receives the posterior the loop ended with (mean, iter, cnvgd, D, t); post: the posterior of
+    a loop already run with THIS convg (calculate_posterior_VL(..., snapshot_convg=convg)["snapshot"]) instead of :369."""
     z = np.asarray(z, dtype=np.float64)
-    post = calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, prior_mean)
+    if post is None:
+        post = calculate_posterior_VL(z, va, likelihood_model, covparms, covmodel, likparms, max_iter, convg, prior_mean,
+                                      sparse=sparse)                   # :369-370
+    if post_out is not None:
+        post_out.update(post)
     if not post["cnvgd"]:
         return -np.inf                                                 # :373
     pm = post["prior_mean"]
@@ -1171,9 +1204,20 @@ def vecchia_laplace_likelihood(z, va, likelihood_model, covparms, likparms=None,
         full = np.full(len(z_pseudo), np.nan)
         full[~np.isnan(z_pseudo)] = D
         D = full
-    marg = vecchia_likelihood(z_pseudo, va, covparms, D, covmodel)     # :396-397
+    marg = (vecchia_likelihood_sparse if sparse else vecchia_likelihood)(z_pseudo, va, covparms, D, covmodel)   # :396-397
     io = ~np.isnan(z)                                                  # :401
     true_llh = post["model_llh"](post["mean"][io], z[io])              # :402
     with np.errstate(invalid="ignore"):
         cond = np.nansum(-0.5 * np.log(2 * np.pi * D) - 0.5 * (z_pseudo - (post["mean"] - pm)) ** 2 / D)   # :405, na.rm
     return marg - cond + true_llh                                      # :408-409
+
+
+def calculate_posterior_VL_sparse(z, va, likelihood_model, covparms, **kw):
+    """calculate_posterior_VL (R/vecchia_laplace_NR.R:31-155) with every Newton step's vecchia_prediction on sparse
+    matrices: config 5 (n = 5e5, m = 30) in about a minute.  Pinned to the dense loop in tests/test_oracle.py."""
+    return calculate_posterior_VL(z, va, likelihood_model, covparms, sparse=True, **kw)
+
+
+def vecchia_laplace_likelihood_sparse(z, va, likelihood_model, covparms, **kw):
+    """vecchia_laplace_likelihood (R/vecchia_laplace_NR.R:361-416) on sparse matrices."""
+    return vecchia_laplace_likelihood(z, va, likelihood_model, covparms, sparse=True, **kw)

@@ -146,3 +146,70 @@ def test_prediction_plan_against_sparse_oracle_n4e4(cond, ordering_pred):
     np.testing.assert_allclose(pred["mu_pred"], mp_ref, rtol=0, atol=RTOL * scale)
     if cond == "SGV":
         assert pred.get("route") == "device"
+
+
+def vl_loop_against_sparse_oracle(G, n, m, cp, seed_z=2, model="poisson"):
+    """The Vecchia-Laplace Newton LOOP (R/vecchia_laplace_NR.R:88-130) and vecchia_laplace_likelihood (:361-416) of the HIP
+    path against the oracle's sparse restatement of the same loop (calculate_posterior_VL_sparse: createU_sparse ->
+    U2V_sparse -> vecchia_mean_sparse per step, pinned to the dense loop in tests/test_oracle.py).  Returns the comparison;
+    used by the test below and by bench.py's secondary.C5_vl.parity_in_run (outside every timed region)."""
+    from oracle import r_side as R
+    locs = np.random.default_rng(0).random((n, 2))
+    y = 0.8 * np.sin(5 * locs[:, 0]) * np.cos(4 * locs[:, 1]) + 0.3       # bench.py's vl_config field (SURVEY.md §8d, C5)
+    z = np.random.default_rng(seed_z).poisson(np.exp(y)).astype(float)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+    post = G.calculate_posterior_VL(z, va, model, cp)
+    ll = G.vecchia_laplace_likelihood(z, va, model, cp)
+    vb = _to_oracle_va(va)
+    tr = []
+    ref = R.calculate_posterior_VL_sparse(z, vb, model, cp, trace=tr, snapshot_convg=1e-5)
+    ll_ref = R.vecchia_laplace_likelihood_sparse(z, vb, model, cp, post=ref["snapshot"])   # (:369: convg = 1e-5 there)
+    scale = max(1.0, np.abs(ref["mean"]).max())
+    diff = np.abs(post["mean"] - ref["mean"]).max() / scale
+    res = dict(n=n, m=m, iters_hip=int(post["iter"]), iters_oracle=int(ref["iter"]), cnvgd_hip=bool(post["cnvgd"]),
+               cnvgd_oracle=bool(ref["cnvgd"]), mean_max_diff=float(diff), mean_abs_max=float(np.abs(ref["mean"]).max()),
+               loglik_hip=float(ll), loglik_oracle=float(ll_ref), loglik_rel_err=float(abs(ll - ll_ref) / abs(ll_ref)),
+               oracle_trace=tr, adjudicated=False, tol=RTOL)
+    if not diff <= RTOL:
+        # whose error?  The last Newton step of the oracle's loop (its pseudo-data and pseudo-variances) once more in x87
+        # extended precision: the exact step from the oracle's y_prev; Newton's map contracts quadratically there, so the
+        # HIP loop's own y_prev (1e-8 away) yields the same exact step to ~1e-16
+        ex = R.posterior_extended(ref["t"], vb, cp, ref["D"])
+        mu_ext = np.empty(n)
+        mu_ext[va["ord"] - 1] = ex["mu_ord"]
+        res.update(adjudicated=True, err_hip=float(np.abs(post["mean"] - mu_ext).max() / scale),
+                   err_oracle=float(np.abs(ref["mean"] - mu_ext).max() / scale))
+    return res
+
+
+def test_vecchia_laplace_loop_against_sparse_oracle_C5_n5e5_m30():
+    """BASELINE config 5 as a LOOP at full size: n = 5e5, m = 30, Poisson data, maxmin + SGV, covparms (1, 0.03, 1.5) —
+    equal iteration count, posterior mean within 1e-8 (or adjudicated in extended precision), likelihood within 1e-8."""
+    G = _need_gpu()
+    res = vl_loop_against_sparse_oracle(G, 500_000, 30, [1.0, 0.03, 1.5])
+    print("vl-loop-vs-oracle", {k: v for k, v in res.items() if k != "oracle_trace"})
+    assert res["cnvgd_hip"] and res["cnvgd_oracle"] and res["iters_hip"] == res["iters_oracle"] >= 3, res
+    if res["adjudicated"]:
+        assert res["err_hip"] <= max(4.0 * res["err_oracle"], RTOL), res
+    else:
+        assert res["mean_max_diff"] <= RTOL
+    assert res["loglik_rel_err"] <= RTOL, res
+
+
+def test_vecchia_laplace_loop_against_sparse_oracle_n4e4_logistic():
+    """The same comparison at a size where it takes seconds, another family, m = 20."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    n, m, cp = 40_000, 20, [0.8, 0.05, 1.5]
+    rng = np.random.default_rng(9)
+    locs = rng.random((n, 2))
+    f = 1.5 * np.sin(4 * locs[:, 0]) * np.cos(3 * locs[:, 1])
+    z = (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float)
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="SGV", nn_backend="gpu")
+    post = G.calculate_posterior_VL(z, va, "logistic", cp)
+    vb = _to_oracle_va(va)
+    ref = R.calculate_posterior_VL_sparse(z, vb, "logistic", cp)
+    assert post["cnvgd"] and ref["cnvgd"] and post["iter"] == ref["iter"]
+    np.testing.assert_allclose(post["mean"], ref["mean"], rtol=0, atol=RTOL * max(1.0, np.abs(ref["mean"]).max()))
+    ll, ll_ref = G.vecchia_laplace_likelihood(z, va, "logistic", cp), R.vecchia_laplace_likelihood_sparse(z, vb, "logistic", cp)
+    assert abs(ll - ll_ref) <= RTOL * abs(ll_ref)

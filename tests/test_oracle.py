@@ -465,3 +465,39 @@ def test_posterior_extended_agrees_with_mpmath_and_brackets_the_double_chain():
     mu_d = R.vecchia_mean_sparse(z, Us, R.U2V_sparse(Us), ordered=True)
     err_dbl = np.abs(mu_d - mu_mp).max() / scale
     assert err_dbl > 20 * err_ext                                      # the adjudicator is the better of the two by far
+
+
+@pytest.mark.parametrize("model,cond,missing", [("poisson", "SGV", False), ("poisson", "SGV", True), ("logistic", "z", False),
+                                                ("gamma", "y", False), ("gaussian", "SGV", True)])
+def test_sparse_vecchia_laplace_loop_equals_the_dense_loop(model, cond, missing):
+    """calculate_posterior_VL_sparse / vecchia_laplace_likelihood_sparse (what the GPU test of BASELINE config 5 uses at
+    n = 5e5) against the dense restatement of R/vecchia_laplace_NR.R:88-130,361-416: same number of Newton steps, same
+    convergence trace, same posterior mean and likelihood — with missing observations (Inf pseudo-nuggets, :107) too."""
+    rng = np.random.default_rng(61)
+    n, m = 1500, 12
+    locs = rng.random((n, 2))
+    f = 0.8 * np.sin(5 * locs[:, 0]) * np.cos(4 * locs[:, 1]) + 0.3
+    z = {"poisson": lambda: rng.poisson(np.exp(f)).astype(float),
+         "logistic": lambda: (rng.random(n) < 1 / (1 + np.exp(-f))).astype(float),
+         "gamma": lambda: rng.gamma(2.0, np.exp(f) / 2.0),
+         "gaussian": lambda: f + np.sqrt(.1) * rng.standard_normal(n)}[model]()
+    if missing:
+        z[rng.choice(n, 40, replace=False)] = np.nan
+    cp = [0.6, 0.12, 1.5]
+    va = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz=cond)
+    td, ts = [], []
+    pd_ = R.calculate_posterior_VL(z, va, model, cp, trace=td)
+    ps = R.calculate_posterior_VL_sparse(z, va, model, cp, trace=ts, snapshot_convg=1e-5)
+    assert pd_["cnvgd"] and ps["cnvgd"] and pd_["iter"] == ps["iter"] >= 2
+    np.testing.assert_allclose(ts, td, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(ps["mean"], pd_["mean"], rtol=0, atol=1e-9 * np.abs(pd_["mean"]).max())   # (removeNAs: nuggets of 1e8 var)
+    np.testing.assert_allclose(ps["D"], pd_["D"], rtol=1e-9)
+    ll_d = R.vecchia_laplace_likelihood(z, va, model, cp)
+    out = {}
+    ll_s = R.vecchia_laplace_likelihood_sparse(z, va, model, cp, post_out=out)
+    assert abs(ll_s - ll_d) <= 1e-10 * abs(ll_d)
+    assert out["iter"] <= pd_["iter"] and out["cnvgd"]                   # (convg 1e-5 there, 1e-6 above)
+    # the snapshot of the 1e-6 loop at 1e-5 IS the 1e-5 loop's result: same step, same arrays, same likelihood
+    snap = ps["snapshot"]
+    assert snap["iter"] == out["iter"] and np.array_equal(snap["mean"], out["mean"]) and np.array_equal(snap["D"], out["D"])
+    assert R.vecchia_laplace_likelihood_sparse(z, va, model, cp, post=snap) == ll_s
