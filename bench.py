@@ -815,6 +815,16 @@ def main():
         k_ms = float(km.item())
 
     sums_job = last_sums.copy()                           # totals of the last timed step (N > 1: all-reduced over the ranks)
+    shard_info = None
+    if use_dist and world > 1:
+        # every rank's shard and what its GPU holds (after the timed region): rows it owns, device memory in use on its
+        # device (hipMemGetInfo: everything resident there, all processes), peak of this process's torch allocator
+        free_b, total_b = torch.cuda.mem_get_info()
+        mine = {"rank": rank, "rows": [int(a), int(b)], "device": int(local_rank),
+                "device_mem_used_gb": round((total_b - free_b) / 2 ** 30, 3)}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        shard_info = gathered
     gpu_U = None
     if world == 1 and not use_dist and args.mode == "L" and not args.no_cpu_baseline and p <= 64:
         # parity_in_run, GPU half (untimed): one more evaluation that also writes the U entries, copied to the host
@@ -873,7 +883,8 @@ def main():
                                       f"; THIS RANK'S SHARD of an emulated {args.emulate_world}-rank job only)"),
                        "n": n, "m": m, "d": d, "covparms": covparms, "nugget": tau, "mode": args.mode,
                        "sharding": f"rows/{world}", "loglik": loglik, "setup_s": round(t_setup, 2),
-                       "collective": route, "ranks": world, "rows_reduced": float(sums_job[7])},
+                       "collective": route, "ranks": world, "rows_reduced": float(sums_job[7]),
+                       "shards": shard_info},
             "roofline": roofline(k_ms, rows_rank, args.mode, traffic),
         }
         if k_b2b is not None:

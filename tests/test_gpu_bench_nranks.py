@@ -70,3 +70,36 @@ def test_a_stalled_rank_trips_the_wall_clock_guard_with_exit_4_and_no_hang():
     assert out is None                                               # no line for a job that did not complete
     assert "exiting 4" in r.stderr
     assert elapsed < 100, elapsed                                    # ended by the guard, not by the sleeper
+
+
+def test_eight_ranks_the_target_world_size_at_full_size_on_one_gpu():
+    """SURVEY.md §8e at the machine's world size: `bench.py --gpus 8 --n 1000000` (BASELINE configs[2]) with eight fresh
+    child ranks sharing GPU 0 over gloo.  Every rank owns 125 000 contiguous rows (src/U_NZentries.cpp:37-39: rows are
+    independent), the all-reduced row count is n, the 8-rank log-likelihood equals the unsharded plan's to 1e-12."""
+    e = dict(os.environ, GPV_BENCH_BACKEND="gloo", PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--n", "1000000", "--steps", "5",
+                        "--warmup", "1", "--no-cpu-baseline", "--no-secondary"], capture_output=True, text=True, timeout=900, env=e)
+    elapsed = time.time() - t0
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "nranks_8.txt"), "w") as f:
+            f.write(f"rc {r.returncode} elapsed {elapsed:.1f} s\n" + (lines[-1] if lines else "") + "\n" + r.stderr)
+    except OSError:
+        pass
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(lines[-1])
+    assert out["n_gpus"] == 8 and out["config"]["ranks"] == 8 and out["config"]["rows_reduced"] == 1_000_000
+    assert out["config"]["sharding"] == "rows/8"
+    sh = sorted(out["config"]["shards"], key=lambda x: x["rank"])
+    assert [x["rank"] for x in sh] == list(range(8))
+    assert all(x["rows"] == [125_000 * i, 125_000 * (i + 1)] for i, x in enumerate(sh))
+    assert all(0 < x["device_mem_used_gb"] < 288 for x in sh)
+    sc = out["self_check"]
+    assert sc["ok"] and sc["rows_ok"] and sc["loglik_ok"] and sc["rel_diff"] <= 1e-12 and sc["ranks"] == 8
+    assert out["roofline"]["sets_per_launch"] == 125_000
+    print(f"8 ranks on one GPU: {elapsed:.1f} s, device memory in use {max(x['device_mem_used_gb'] for x in sh)} GB")
+    assert elapsed <= 180, elapsed                                    # (eight torch imports and eight HIP contexts on one box)
