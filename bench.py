@@ -266,6 +266,20 @@ def kernel_code_sha256():
     return hashlib.sha256("".join(src.split()).encode()).hexdigest()
 
 
+def posterior_code_sha256():
+    """Hash of the posterior pass's CODE (gpv_posterior.hip, comments and whitespace removed) and of the schedule builder's
+    (gpv_api.hip build_posterior_impl lives in gpv_api.hip: the whole file): offline per-level counters under profiles/ are
+    quoted only while both are the code they were measured on."""
+    import re
+    h = hashlib.sha256()
+    for f in ("gpv_posterior.hip", "gpv_posterior_ext.h"):
+        src = open(os.path.join(ROOT, "gpvecchia_amd", "csrc", f), encoding="utf-8").read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        src = re.sub(r"//[^\n]*", "", src)
+        h.update("".join(src.split()).encode())
+    return h.hexdigest()
+
+
 def count_gpus_sysfs():
     """GPUs of this box counted from the KFD topology in sysfs (nodes with simd_count > 0), honouring the
     HIP/ROCR_VISIBLE_DEVICES lists: the launching parent never opens the driver, not even to count devices."""
@@ -917,19 +931,31 @@ def main():
                     try:
                         # the posterior pass against ITS roofline: L2 line misses (a scattered 16-byte gather moves one 128-byte
                         # line; the chip serves ~54 such lines per ns: tools/ubench/gather_lines.hip) per
-                        # nanosecond of pass.  Misses: the per-level counters of this workload under profiles/ (PMC passes cannot
-                        # run inside a timed bench); pass time: this run's evaluation minus its set kernel.
-                        lv = json.load(open(os.path.join(ROOT, "profiles", "r05_posterior_levels_pmc.json")))
-                        misses = sum(v.get("TCC_MISS_sum", 0.0) for v in lv.values())
+                        # nanosecond of pass.  DERIVED FROM OFFLINE COUNTERS: the misses are the per-level PMC sums of this
+                        # workload under profiles/ (PMC passes cannot run inside a timed bench), quoted only while the file
+                        # says it was measured on the pass code of this tree (`_meta.posterior_code_sha256`); otherwise the
+                        # block says "stale" and carries no fraction.  Pass time: this run's evaluation minus its set kernel.
+                        import glob
                         pass_ms = 1e3 * el / args.steps - km
-                        pass_roof = {"bound": "l2_miss_lines", "pass_ms": pass_ms, "l2_line_misses": misses,
-                                     "achieved": misses / (pass_ms * 1e6), "peak": 54.0, "unit": "128-byte lines/ns",
-                                     "frac": misses / (pass_ms * 1e6) / 54.0,
-                                     "note": "pass_ms = evaluation - set kernel (includes the dense top block, the two "
-                                             "reduction kernels and the launch floor of ~45 narrow levels); misses from "
-                                             "profiles/r05_posterior_levels_pmc.json (same workload)"}
-                    except Exception:
-                        pass_roof = None
+                        pass_roof = {"stale": True, "pass_ms": pass_ms, "derived_from": "offline counters",
+                                     "note": "no profiles/r*_posterior_levels_pmc.json measured on this tree's posterior code"}
+                        for lf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_posterior_levels_pmc.json")), reverse=True):
+                            lv = json.load(open(lf))
+                            meta = lv.get("_meta", {})
+                            if meta.get("posterior_code_sha256") != posterior_code_sha256():
+                                continue
+                            misses = sum(v.get("TCC_MISS_sum", 0.0) for k_, v in lv.items() if k_ != "_meta")
+                            pass_roof = {"bound": "l2_miss_lines", "stale": False, "pass_ms": pass_ms, "l2_line_misses": misses,
+                                         "achieved": misses / (pass_ms * 1e6), "peak": 54.0, "unit": "128-byte lines/ns",
+                                         "frac": misses / (pass_ms * 1e6) / 54.0,
+                                         "derived_from": "offline counters: " + os.path.basename(lf),
+                                         "counters_code_sha256": meta.get("posterior_code_sha256"),
+                                         "note": "pass_ms = evaluation - set kernel (includes the dense top block, the two "
+                                                 "reduction kernels and the launch floor of the narrow levels); misses: "
+                                                 "per-level PMC sums of the same workload, measured offline on this pass code"}
+                            break
+                    except Exception as e:                    # noqa: BLE001
+                        pass_roof = {"stale": True, "error": repr(e)}
                     sec["mode_S"] = {"value": args.steps / el, "unit": "evals/s", "ms_per_step": 1e3 * el / args.steps,
                                      "sets_kernel_ms": km, "loglik": ll, "levels": nlev, "setup_s": round(ts, 2),
                                      "what": "the reference's defaults: ordering='maxmin', cond.yz='SGV'; set kernel + "

@@ -32,7 +32,7 @@ EXPORTS = [
     "gpv_plan_Lentries_device", "gpv_plan_rows", "gpv_plan_dims", "gpv_plan_last_kernel_ms", "gpv_plan_set_kernel_timing",
     "gpv_loglik_z_from_sums", "gpv_numerator_from_sums", "gpv_whichCondOnLatent",
     "gpv_plan_build_posterior", "gpv_plan_build_posterior_fill", "gpv_plan_posterior_levels", "gpv_loglik_from_sums", "gpv_plan_get_posterior_mean", "gpv_find_ordered_nn", "gpv_order_maxmin_exact", "gpv_ic0",
-    "gpv_plan_cache_clear", "gpv_plan_cache_stats", "gpv_plan_vl_begin", "gpv_plan_vl_step", "gpv_plan_vl_get",
+    "gpv_plan_cache_clear", "gpv_plan_cache_stats", "gpv_hash_bytes", "gpv_plan_vl_begin", "gpv_plan_vl_step", "gpv_plan_vl_get",
     "gpv_plan_set_user_order", "gpv_plan_vl_begin_user", "gpv_plan_vl_restart", "gpv_plan_vl_get_user", "gpv_plan_vl_loglik",
     "gpv_mplan_create", "gpv_mplan_destroy", "gpv_mplan_set_data", "gpv_mplan_eval", "gpv_mplan_get_Lentries",
     "gpv_mplan_create_replicas", "gpv_mplan_count", "gpv_mplan_set_data_one", "gpv_mplan_build_posterior",
@@ -122,6 +122,7 @@ def lib():
     L.gpv_find_ordered_nn.argtypes = [C.c_int, dp, i64, C.c_int, C.c_int, i64, i64, ip]
     L.gpv_whichCondOnLatent.argtypes = [ip, i64, C.c_int, i64, ip]
     L.gpv_plan_cache_stats.argtypes = [C.POINTER(i64), C.POINTER(i64)]
+    L.gpv_hash_bytes.argtypes = [vp, i64, C.c_uint64, C.POINTER(C.c_uint64)]
     L.gpv_plan_vl_begin.argtypes = [vp, C.c_int, dp, dp, dp, dp]
     L.gpv_plan_vl_step.argtypes = [vp, C.c_char_p, dp, C.c_int, dp, ip]
     L.gpv_plan_vl_get.argtypes = [vp, dp, dp, dp]

@@ -49,6 +49,7 @@ class Plan:
 
     def build_posterior(self):
         """Structure of the U2V pass (R/vecchia_prediction.R:62-83) for GPV_WANT_DENOM evaluations."""
+        self.has_posterior = False                       # the library drops any earlier structure on entry: true only on success
         L.check(L.lib().gpv_plan_build_posterior(self._h, L.iptr(self._nn), L.iptr(self._cd)), "gpv_plan_build_posterior")
         self.has_posterior = True
         nl = C.c_int()
@@ -63,6 +64,7 @@ class Plan:
             return True
         if getattr(self, "_post_refused", False):
             return False
+        self.has_posterior = False                       # the library drops any earlier structure on entry: true only on success
         st = L.lib().gpv_plan_build_posterior(self._h, L.iptr(self._nn), L.iptr(self._cd))
         if st == 5:
             self._post_refused = True
@@ -78,6 +80,7 @@ class Plan:
         if getattr(self, "_fill_refused", False):
             return None
         ratio = C.c_double(0.0)
+        self.has_posterior = False                       # (as in ensure_posterior: a refused or failed rebuild leaves none)
         st = L.lib().gpv_plan_build_posterior_fill(self._h, L.iptr(self._nn), L.iptr(self._cd), float(max_fill), C.byref(ratio))
         if st == 5:                                       # GPV_ERR_UNSUPPORTED_M: bounded out
             self._fill_refused = True
@@ -334,6 +337,7 @@ class ReplicaPlans:
             L.check(L.lib().gpv_mplan_set_data_one(self._h, int(replica), L.dptr(z)), "gpv_mplan_set_data_one")
 
     def build_posterior(self):
+        self.has_posterior = False
         L.check(L.lib().gpv_mplan_build_posterior(self._h, L.iptr(self._nn), L.iptr(self._cd)), "gpv_mplan_build_posterior")
         self.has_posterior = True
 
@@ -361,19 +365,17 @@ _R_LAYOUT_CACHE = []          # [(weakref(revNNarray), weakref(revCond), fingerp
 
 
 def _fingerprint(a):
-    """Content fingerprint of an index array: shape, dtype and a hash of EVERY byte (xxh3-128 where the xxhash module is
-    there, ~10 GB/s: ~15 ms for the two arrays of n = 1e6, m = 30; zlib.crc32 otherwise).  An in-place edit of the array
-    between two calls changes it."""
+    """Content fingerprint of an index array: shape, dtype, strides and the library's 128-bit hash of EVERY byte
+    (gpv_hash_bytes: the multi-threaded hash the plan cache of the literal drop-in keys on, ~3-4 ms for the two arrays of
+    n = 1e6, m = 30; no optional module, no 32-bit fallback).  An in-place edit of the array between two calls changes it.
+    None for an empty array (nothing worth caching)."""
     a = np.asarray(a)
+    if a.size == 0:
+        return None
     buf = a if a.flags.c_contiguous or a.flags.f_contiguous else np.ascontiguousarray(a)
-    mv = memoryview(buf.reshape(-1, order="A")).cast("B")
-    try:
-        import xxhash
-        dig = xxhash.xxh3_128_digest(mv)
-    except ImportError:
-        import zlib
-        dig = zlib.crc32(mv)
-    return (a.shape, a.dtype.str, a.strides, dig)
+    out = (C.c_uint64 * 2)()
+    L.check(L.lib().gpv_hash_bytes(C.c_void_p(buf.ctypes.data), buf.nbytes, 0x6770765F6670, out), "gpv_hash_bytes")
+    return (a.shape, a.dtype.str, a.strides, int(out[0]), int(out[1]))
 
 
 def _r_layout_cached(revNNarray, revCond):
@@ -383,6 +385,8 @@ def _r_layout_cached(revNNarray, revCond):
     unchanged hash of their whole content, so an array edited in place between two calls is converted again."""
     import weakref
     fp = (_fingerprint(revNNarray), _fingerprint(revCond))
+    if fp[0] is None or fp[1] is None:                                 # empty arrays: convert, do not cache
+        return L.as_r_int_matrix(revNNarray), _cond_to_r(revCond)
     for wa, wb, f, nn_r, cd_r in _R_LAYOUT_CACHE:
         if wa() is revNNarray and wb() is revCond and f == fp:
             return nn_r, cd_r

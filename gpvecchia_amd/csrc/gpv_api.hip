@@ -19,6 +19,7 @@
 #include <cstring>
 #include <algorithm>
 #include <atomic>
+#include <limits>
 #include <mutex>
 #include <numeric>
 #include <thread>
@@ -1062,6 +1063,16 @@ static int plan_eval_impl(gpv_plan *pl, const CovSetup &cs, const double *nugget
     return GPV_OK;
 }
 
+// every caller's way into plan_eval_impl: an evaluation that failed after its launch may have started leaves the arrival
+// counter of the fused reduction mid-count; the next evaluation of the plan resets it first
+static int plan_eval_checked(gpv_plan *pl, const CovSetup &cs, const double *nuggets, int64_t n_nuggets, int flags,
+                             void *stream, double *d_sums_out)
+{
+    const int rc = plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
+    if (rc != GPV_OK && rc != GPV_ERR_BAD_ARG) pl->ticket_dirty = true;
+    return rc;
+}
+
 int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int ncovparms, const double *nuggets,
                   int64_t n_nuggets, int flags, void *stream, double *d_sums_out)
 {
@@ -1069,9 +1080,7 @@ int gpv_plan_eval(gpv_plan *pl, const char *covType, const double *covparms, int
     CovSetup cs;
     const int st = cov_setup(covType, covparms, ncovparms, cs);
     if (st != GPV_OK) return st;
-    const int rc = plan_eval_impl(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
-    if (rc != GPV_OK && rc != GPV_ERR_BAD_ARG) pl->ticket_dirty = true;   // a launch may have been cut short: reset the counter next time
-    return rc;
+    return plan_eval_checked(pl, cs, nuggets, n_nuggets, flags, stream, d_sums_out);
 }
 
 int gpv_rccl_version(void)
@@ -1765,7 +1774,7 @@ static int vl_step_enqueue(gpv_plan *pl, const char *covType, const double *covp
         GPV_HIP(launch_vl_fill_missing(pl->d_vl_z, pl->Nlocs, pl->d_newpos, data_int, dstr, doff, pl->d_zuser, pl->d_nuggets,
                                        pl->d_nug_user, pl->d_vl_part, st));
     // vecchia_prediction(pseudo.data, nuggets = D, return.values = 'meanmat') (:112-113)
-    const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_MEAN, st, nullptr);
+    const int rc = plan_eval_checked(pl, cs, nullptr, -1, GPV_WANT_MEAN, st, nullptr);
     if (rc != GPV_OK) return rc;
     // :115-117; the step's two scalars (max |dy| and the flag word) land in pinned host memory: no copy command
     GPV_HIP(launch_vl_update(pl->d_mu, pl->d_vl_pm, y, pl->d_vl_z, ynew, pl->Nlocs, pl->d_post_part, pl->d_vl_out, pl->d_vl_flags,
@@ -1855,7 +1864,7 @@ int gpv_plan_vl_loglik(gpv_plan *pl, const char *covType, const double *covparms
     hipStream_t st = pl->stream;
     GPV_HIP(launch_vl_terms(pl->vl_model, pl->vl_alpha, pl->vl_sigma, pl->vl_beta, pl->d_vl_y[pl->vl_cur], pl->d_vl_z, pl->d_vl_pm,
                             pl->d_zuser, pl->d_nug_user, pl->Nlocs, pl->d_vl_part, pl->d_vl_out + 2, st));
-    const int rc = plan_eval_impl(pl, cs, nullptr, -1, GPV_WANT_DENOM, st, nullptr);
+    const int rc = plan_eval_checked(pl, cs, nullptr, -1, GPV_WANT_DENOM, st, nullptr);
     if (rc != GPV_OK) return rc;
     double sums[GPV_NSUMS], two[2];
     GPV_HIP(hipMemcpyAsync(two, pl->d_vl_out + 2, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
@@ -2091,6 +2100,16 @@ struct PlanCache {
 PlanCache g_cache;
 }  // namespace
 
+int gpv_hash_bytes(const void *ptr, int64_t bytes, uint64_t seed, uint64_t *out2)
+{
+    if ((!ptr && bytes > 0) || bytes < 0 || !out2) return GPV_ERR_BAD_ARG;
+    static const unsigned char none = 0;
+    const Hash128 h = hash_bytes(bytes > 0 ? ptr : &none, (size_t)bytes, seed);
+    out2[0] = h.a;
+    out2[1] = h.b;
+    return GPV_OK;
+}
+
 int gpv_plan_cache_clear(void)
 {
     std::lock_guard<std::mutex> g(g_cache.mu);
@@ -2157,6 +2176,18 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
     static const bool no_cache = getenv("GPV_NO_PLAN_CACHE") != nullptr;
     std::unique_lock<std::mutex> cache_lock(g_cache.mu, std::defer_lock);
     bool cached = false, evaluated = false;
+    // The speculative evaluation copies the CACHED plan's U entries into the caller's Lentries before the content hash has said
+    // whose plan that is.  If the hash then does not match and the rebuild or its evaluation fails, those values must not stay
+    // there looking like results: every exit with an error behind a speculative write fills Lentries with NaN.
+    bool spec_wrote = false;
+    auto fail = [&](int code) {
+        if (spec_wrote) {
+            const size_t cnt = (size_t)*Nlocs * (size_t)*ncolNN;
+            const double nanv = std::numeric_limits<double>::quiet_NaN();
+            for (size_t e = 0; e < cnt; ++e) Lentries[e] = nanv;
+        }
+        *status = code;
+    };
     if (!no_cache && *Nlocs > 0 && *dim > 0 && *ncolNN > 0) {
         cache_lock.lock();                                   // the cached plan is in use until this call returns
         const size_t nl = (size_t)*Nlocs;
@@ -2175,9 +2206,10 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
         // rebuilt and everything is computed again over them.
         int rc_spec = GPV_OK;
         const bool spec = g_cache.pl && g_cache.Nlocs == *Nlocs && g_cache.dim == *dim && g_cache.ncol == *ncolNN;
+        spec_wrote = spec;
         if (spec) {
             std::thread hasher(hash_all, 12u);
-            rc_spec = plan_eval_impl(g_cache.pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
+            rc_spec = plan_eval_checked(g_cache.pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
             if (rc_spec == GPV_OK) rc_spec = gpv_plan_get_Lentries(g_cache.pl, Lentries);
             hasher.join();
             tm.lap("drop-in: content hash over nuggets H2D + kernel + transpose + D2H");
@@ -2196,7 +2228,7 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
             g_cache.pl = nullptr;
             ++g_cache.misses;
             rc = gpv_plan_create(&pl, 0, *Nlocs, *dim, *ncolNN, locs, revNNarray, revCondOnLatent, 0, *Nlocs);
-            if (rc != GPV_OK) { *status = rc; return; }
+            if (rc != GPV_OK) { fail(rc); return; }
             g_cache.pl = pl;
             g_cache.Nlocs = *Nlocs; g_cache.dim = *dim; g_cache.ncol = *ncolNN;
             g_cache.h_locs = hl; g_cache.h_nn = hn; g_cache.h_cond = hc;
@@ -2208,7 +2240,7 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
     }
     tm.lap("drop-in: plan");
     if (!evaluated) {
-        rc = plan_eval_impl(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
+        rc = plan_eval_checked(pl, cs, nuggets, *Nlocs, GPV_WANT_U, nullptr, nullptr);
         if (rc == GPV_OK && tm.on) (void)hipStreamSynchronize(pl->stream);
         tm.lap("drop-in: nuggets H2D + kernel");
         if (rc == GPV_OK) rc = gpv_plan_get_Lentries(pl, Lentries);
@@ -2226,7 +2258,8 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
         g_cache.pl = nullptr;
     }
     tm.lap("drop-in: destroy");
-    *status = rc;
+    if (rc != GPV_OK) fail(rc);
+    else *status = rc;
 }
 
 void gpv_U_NZentries_mat(const int *Ncores, const int *n, const int *Nlocs, const int *ncolNN, const int *revNNarray,

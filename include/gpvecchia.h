@@ -127,6 +127,10 @@ void gpv_U_NZentries(const int *Ncores, const int *n, const int *Nlocs, const in
  * the environment variable GPV_NO_PLAN_CACHE=1 disables the cache.  Calls are serialised on the cache. */
 int gpv_plan_cache_clear(void);
 int gpv_plan_cache_stats(int64_t *hits, int64_t *misses);   /* counters since load (either pointer may be NULL) */
+/* The 128-bit content hash the plan cache keys on (multi-threaded, result independent of the thread count; not
+ * cryptographic), for host code that wants to key a cache of its own on the same arrays: out2[0..1] = hash of `bytes` bytes
+ * at ptr under `seed`.  bytes == 0 is valid (ptr may be NULL then). */
+int gpv_hash_bytes(const void *ptr, int64_t bytes, uint64_t seed, uint64_t *out2);
 
 /* Replaces: _GPvecchia_U_NZentries_mat (src/RcppExports.cpp:70-86), R/RcppExports.R:26-28,
  * body src/U_NZentries.cpp:126-197, call site R/createU.R:149-151.

@@ -17,6 +17,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from oracle import r_side as R   # noqa: E402
 
 
+PROVENANCE = ("oracle-generated (oracle/r_side.py + oracle/u_nzentries_oracle.c through this script): a REGRESSION fixture, NOT output of the "
+              "GPvecchia package; every field, the posterior quantities V_diag / logdet_denom / quadform_denom / mu_obs included, "
+              "comes from the oracle itself.  The only parity pin would be tests/golden/reference_run/ (make_golden_reference.R, never run: "
+              "no R in this image)")
+
+
 def case(name, locs, z, m, ordering, cond, covmodel, covparms, nuggets):
     va = R.vecchia_specify(locs, m, ordering=ordering, cond_yz=cond)
     U = R.createU(va, covparms, nuggets, covmodel)
@@ -32,7 +38,7 @@ def case(name, locs, z, m, ordering, cond, covmodel, covparms, nuggets):
     z3 = np.linalg.solve(V, z2[::-1])                                              # R/vecchia_likelihood.R:88 (V lower triangular)
     post = dict(mu_obs=mu_obs, logdet_denom=-2 * np.sum(np.log(np.diag(V))), quadform_denom=np.sum(z3 ** 2),
                 V_diag=np.diag(V).copy())
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), locs=locs, z=z, m=m, ordering=ordering, cond=cond, **post,
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), provenance=PROVENANCE, locs=locs, z=z, m=m, ordering=ordering, cond=cond, **post,
                         covmodel=covmodel, covparms=np.asarray(covparms, float), nuggets=np.asarray(nuggets, float),
                         ord=va["ord"], revNNarray=np.nan_to_num(prep["revNNarray"]).astype(np.int32),
                         revCond=np.nan_to_num(prep["revCond"], nan=-1).astype(np.int8),

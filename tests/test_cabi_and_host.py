@@ -340,3 +340,32 @@ def test_vecchia_laplace_data_support_checks():
     assert not _families("poisson", lp)["bad"](big)
     big[123_456] += 0.25
     assert _families("poisson", lp)["bad"](big)
+
+
+def test_hash_bytes_and_index_array_fingerprint():
+    """gpv_hash_bytes (include/gpvecchia.h): deterministic, independent of the thread count by construction, every byte
+    counts, empty input valid; gpvecchia_amd.api._fingerprint keys the R-layout cache on it (no optional module, no
+    32-bit fallback) and skips empty arrays."""
+    import ctypes as C
+    from gpvecchia_amd import _lib as L, api as A
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 1000, size=(70_000, 31), dtype=np.int32)          # > 4 MiB: the 64-chunk threaded form
+
+    def h(x, seed=5):
+        out = (C.c_uint64 * 2)()
+        assert L.lib().gpv_hash_bytes(C.c_void_p(x.ctypes.data), x.nbytes, seed, out) == 0
+        return int(out[0]), int(out[1])
+    assert h(a) == h(a.copy()) and h(a) != h(a, seed=6)
+    b = a.copy(); b[69_999, 30] ^= 1
+    c = a.copy(); c[0, 0] ^= 1 << 30
+    assert len({h(a), h(b), h(c)}) == 3
+    small = np.arange(13, dtype=np.uint8)                                  # tail bytes (13 % 8 != 0), single chunk
+    s2 = small.copy(); s2[12] += 1
+    assert h(small) != h(s2)
+    out = (C.c_uint64 * 2)()
+    assert L.lib().gpv_hash_bytes(None, 0, 1, out) == 0 and L.lib().gpv_hash_bytes(None, 8, 1, out) != 0
+    assert A._fingerprint(np.zeros((0, 5), np.int32)) is None
+    f1, f2 = A._fingerprint(a), A._fingerprint(b)
+    assert f1 != f2 and f1 == A._fingerprint(a) and A._fingerprint(np.asfortranarray(a)) != f1   # (strides are part of it)
+    nn_r, cd_r = A._r_layout_cached(np.zeros((0, 5), np.int32), np.zeros((0, 5), np.int8))
+    assert nn_r.shape == (0, 5) and cd_r.shape == (0, 5)

@@ -24,8 +24,11 @@ def test_kat_matches_survey_values():
 
 @pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
 def test_oracle_reproduces_golden(path):
+    """A REGRESSION check of the oracle against its own frozen output (the fixtures say so themselves: `provenance`), not a
+    parity pin: the reference package never produced these numbers (tests/test_reference_run.py would be that pin)."""
     from oracle import r_side as R
     g = _load(path)
+    assert "oracle-generated" in str(g["provenance"]) and "NOT output of the GPvecchia package" in str(g["provenance"])
     va = R.vecchia_specify(g["locs"], int(g["m"]), ordering=str(g["ordering"]), cond_yz=str(g["cond"]))
     assert np.array_equal(va["ord"], g["ord"])
     assert np.array_equal(np.nan_to_num(va["U_prep"]["revNNarray"]).astype(np.int32), g["revNNarray"])

@@ -502,6 +502,42 @@ def test_literal_dropin_plan_cache():
     _lib.lib().gpv_plan_cache_clear()
 
 
+def test_literal_dropin_failure_behind_a_speculative_evaluation_leaves_no_stale_rows():
+    """gpv_U_NZentries evaluates a cached plan of the right SHAPE at once and hashes the arrays meanwhile: its U
+    entries are in the caller's buffer before the hash has spoken.  When the hash then misses and the rebuild fails (here: an
+    index beyond Nlocs), the caller must not be left with the stale plan's plausible values: status != 0 AND every entry NaN."""
+    import ctypes as C
+    G = _need_gpu()
+    from gpvecchia_amd import _lib as L
+    n, m = 2500, 12
+    locs, z, va = _case(n, m, 2, 12, "z")
+    prep = va["U_prep"]
+    lf = np.asfortranarray(va["locsord"])
+    nn = np.asfortranarray(np.nan_to_num(prep["revNNarray"]).astype(np.int32))
+    cd = np.asfortranarray(np.where(np.isnan(prep["revCond"]), L.NA_INTEGER, np.nan_to_num(prep["revCond"])).astype(np.int32))
+    nug, cp = np.full(n, 0.1), np.array([1.0, 0.1, 1.5])
+    p = nn.shape[1]
+    ci = lambda v: C.byref(C.c_int(int(v)))
+
+    def call(nn_):
+        Lent, Z = np.full((n, p), 7.0, order="F"), np.empty(2 * n)
+        nfail, status, ct = C.c_int(0), C.c_int(0), C.c_char_p(b"matern")
+        L.lib().gpv_U_NZentries(ci(1), ci(n), ci(n), ci(2), ci(p), L.dptr(lf), L.iptr(nn_), L.iptr(cd), L.dptr(nug), L.dptr(nug),
+                                C.byref(ct), L.dptr(cp), ci(3), L.dptr(Lent), L.dptr(Z), C.byref(nfail), C.byref(status))
+        return status.value, Lent
+    L.lib().gpv_plan_cache_clear()
+    st, good = call(nn)
+    assert st == 0 and np.isfinite(good).all()
+    bad = nn.copy(order="F")
+    bad[n - 1, 0] = n + 5                                        # same shape: the speculative evaluation runs; the rebuild refuses
+    st, out = call(bad)
+    assert st != 0
+    assert np.isnan(out).all(), "stale U entries of the cached plan left in the caller's buffer behind a failed call"
+    st, again = call(nn)                                         # and the cache recovers
+    assert st == 0 and np.array_equal(again, good)
+    L.lib().gpv_plan_cache_clear()
+
+
 def test_U_NZentries_mat():
     G = _need_gpu()
     from oracle import r_side as R

@@ -330,3 +330,39 @@ def test_device_posterior_for_long_rows_when_the_latent_entries_fit():
         ll = G.vecchia_likelihood(z, va, cp, tau)
         ll_ref = R.vecchia_likelihood(z, vb, cp, tau)
         assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
+
+
+def test_long_rows_vecchia_laplace_loop_and_zy_on_generic_plans():
+    """m + 1 = 71 (the generic set kernel, P > 64) on the two routes round 5 opened to such plans without a test: the
+    Vecchia-Laplace Newton loop on a cond.yz = 'z' plan (device loop: family kernel + evaluation with GPV_WANT_MEAN per step,
+    R/vecchia_laplace_NR.R:88-130) and cond.yz = 'zy' (V.ord is the reversed latent block, R/vecchia_prediction.R:68-70: the
+    mean_b route), both against the oracle."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(33)
+    n, m = 1200, 70
+    locs = rng.random((n, 2))
+    f = 0.8 * np.sin(5 * locs[:, 0]) * np.cos(4 * locs[:, 1]) + 0.3
+    zc = rng.poisson(np.exp(f)).astype(float)
+    cp = [0.7, 0.12, 1.5]
+    va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="z")
+    vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="z")
+    post = G.calculate_posterior_VL(zc, va, "poisson", cp)
+    ref = R.calculate_posterior_VL_sparse(zc, vb, "poisson", cp)
+    assert post["cnvgd"] and ref["cnvgd"] and post["iter"] == ref["iter"]
+    np.testing.assert_allclose(post["mean"], ref["mean"], rtol=0, atol=1e-8 * max(1.0, np.abs(ref["mean"]).max()))
+    ll, ll_ref = G.vecchia_laplace_likelihood(zc, va, "poisson", cp), R.vecchia_laplace_likelihood_sparse(zc, vb, "poisson", cp)
+    assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)
+    # 'zy'
+    z = rng.standard_normal(n)
+    tau = 0.05 + 0.2 * rng.random(n)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        va = G.vecchia_specify(locs, m, ordering="maxmin", cond_yz="zy")
+        vb = R.vecchia_specify(locs, m, ordering="maxmin", cond_yz="zy")
+        pred = G.vecchia_prediction(z, va, cp, tau)
+        mo_ref = R.vecchia_prediction_mean(z, vb, cp, tau)
+        np.testing.assert_allclose(pred["mu_obs"], mo_ref, rtol=0, atol=1e-8 * np.abs(mo_ref).max())
+        ll, ll_ref = G.vecchia_likelihood(z, va, cp, tau), R.vecchia_likelihood(z, vb, cp, tau)
+    assert abs(ll - ll_ref) <= 1e-8 * abs(ll_ref)

@@ -27,7 +27,13 @@ for p in range(1, 6):
                 per[d]["_grid"] = r.get("Grid_Size", "")
         for li, d in enumerate(sorted(order)):
             res.setdefault(li, {}).update({k: v for k, v in per[d].items()})
+import sys
+sys.path.insert(0, os.getcwd())
+import bench
+res["_meta"] = {"posterior_code_sha256": bench.posterior_code_sha256(),
+                "what": "per-level PMC sums of bench.py --mode S (n = 1e6, m = 30, maxmin + SGV), GPV_NO_GRAPH=1, one evaluation"}
 json.dump(res, open(f"{OUT}/levels_pmc.json", "w"), indent=0)
+res.pop("_meta")
 tot = collections.defaultdict(float)
 for li, d in res.items():
     for k, v in d.items():
