@@ -131,6 +131,27 @@ def marshal_cpu_sample(locs, revNN, revCond, covparms, tau, rows_sample):
     return ms, time.perf_counter() - t0, full
 
 
+def cgroup_cpu_state():
+    """CPU quota and throttling counters of this process's control group (v2: cpu.max / cpu.stat; v1: cpu.cfs_quota_us /
+    cpu.stat), or {} where they cannot be read: a container may see every CPU of the box in its affinity mask and still be
+    held to a fraction of them by a quota."""
+    out = {}
+    try:
+        if os.path.exists("/sys/fs/cgroup/cpu.max"):
+            out["cpu_max"] = open("/sys/fs/cgroup/cpu.max").read().strip()
+            st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+            out["nr_throttled"], out["throttled_usec"] = int(st.get("nr_throttled", 0)), int(st.get("throttled_usec", 0))
+        elif os.path.exists("/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+            q = open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read().strip()
+            per = open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()
+            out["cpu_max"] = f"{'max' if q == '-1' else q} {per}"
+            st = dict(l.split() for l in open("/sys/fs/cgroup/cpu/cpu.stat"))
+            out["nr_throttled"], out["throttled_usec"] = int(st.get("nr_throttled", 0)), int(st.get("throttled_time", 0)) // 1000
+    except (OSError, ValueError):
+        pass
+    return out
+
+
 def time_oracle_function(ms, threads, repeats, probe=None):
     """Seconds of `repeats` calls of the C function oracle_U_NZentries ALONE ("wall-clock of the function
     only"): the ctypes function object on pre-marshalled arguments, nothing else between the two clock reads.  `probe`
@@ -140,9 +161,11 @@ def time_oracle_function(ms, threads, repeats, probe=None):
         probe(fn)
     times = []
     for _ in range(repeats):
+        c0 = time.process_time()
         t0 = time.perf_counter()
         nf = fn(*cargs)
         times.append(time.perf_counter() - t0)
+        time_oracle_function.last_cpu_s = time.process_time() - c0     # CPU seconds of all threads over the last call
     return times, int(nf)
 
 
@@ -158,29 +181,43 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, ke
     n = locs.shape[0]
     logical, physical = host_cpu_topology()
     ms, marshal_s, full = marshal_cpu_sample(locs, revNN, revCond, covparms, tau, rows_sample)
+    cg0 = cgroup_cpu_state()
     times, nfail = time_oracle_function(ms, logical, repeats, probe)
+    cpu_s_last = time_oracle_function.last_cpu_s
     if keep is not None:
         keep["Lentries"] = ms.L[: b - a]
         keep["n_failed"] = nfail
         keep["rows"] = (a, b)
     t = float(np.median(times))
     sets_per_s = (b - a) / t
-    sw = [{"threads": logical, "rows": b - a, "seconds": t, "sets_per_s": sets_per_s}]
+
+    def entry(threads, rows, secs, cpu_s):
+        # effective_cores = CPU seconds the call consumed / its wall time: what the host actually granted the threads
+        return {"threads": threads, "rows": rows, "seconds": secs, "sets_per_s": rows / secs,
+                "effective_cores": round(cpu_s / max(times_last(secs), 1e-9), 1)}
+    times_last = lambda secs: secs
+    sw = [entry(logical, b - a, t, cpu_s_last * t / max(times[-1], 1e-9))]
     if sweep:
-        if physical != logical:
-            tp, _ = time_oracle_function(ms, physical, repeats, probe)
-            tp = float(np.median(tp))
-            sw.append({"threads": physical, "rows": b - a, "seconds": tp, "sets_per_s": (b - a) / tp})
-        # one thread: a bounded row sample (full rows, n0 = m + 1) — the whole data set would take ~20 s per repeat
+        for th in sorted({physical, 32, 8} - {logical, 1}, reverse=True):
+            if th > logical:
+                continue
+            tp, _ = time_oracle_function(ms, th, 2 if th != physical else repeats, probe)
+            cpu_th = time_oracle_function.last_cpu_s * float(np.median(tp)) / max(tp[-1], 1e-9)
+            sw.append(entry(th, b - a, float(np.median(tp)), cpu_th))
+        # one thread: a bounded row sample (full rows, n0 = m + 1) — the whole data set would take ~10-20 s per repeat
         r1 = min(b - a, 60000)
         if r1 == b - a:
             m1 = ms
         else:
             m1, _, _ = marshal_cpu_sample(locs, revNN, revCond, covparms, tau, (b - r1, b))
         t1, _ = time_oracle_function(m1, 1, 2, probe)
-        t1 = float(np.median(t1))
-        sw.append({"threads": 1, "rows": r1, "seconds": t1, "sets_per_s": r1 / t1})
+        sw.append(entry(1, r1, float(np.median(t1)), time_oracle_function.last_cpu_s * float(np.median(t1)) / max(t1[-1], 1e-9)))
         sw.sort(key=lambda e: e["threads"])
+    cg1 = cgroup_cpu_state()
+    cgroup = dict(cg1)
+    if "throttled_usec" in cg0 and "throttled_usec" in cg1:
+        cgroup["throttled_usec_during_baseline"] = cg1["throttled_usec"] - cg0["throttled_usec"]
+        cgroup["nr_throttled_during_baseline"] = cg1["nr_throttled"] - cg0["nr_throttled"]
     what = ("oracle/u_nzentries_oracle.c oracle_U_NZentries, the C function ALONE on pre-marshalled arguments (ctypes call "
             f"between two clock reads; marshalling {marshal_s:.2f} s reported apart as marshal_s)")
     if full:
@@ -192,6 +229,7 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, ke
                   f"EXTRAPOLATED linearly to n")
     return dict(value=sets_per_s / n, unit="evals/s", cores=logical, physical_cores=physical, kind="port", sample=sample,
                 extrapolated=not full, sets_per_s=sets_per_s, seconds=t, marshal_s=marshal_s, thread_sweep=sw,
+                cgroup=cgroup, loadavg=[round(x, 1) for x in os.getloadavg()],
                 timed_callable="ctypes oracle_U_NZentries",
                 note="own C restatement of src/U_NZentries.cpp:39-69 without Armadillo's per-iteration temporaries: "
                      "FASTER than the real reference (BASELINE.md §2), which cannot be built on this box")

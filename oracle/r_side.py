@@ -42,7 +42,8 @@ def build_c_oracle(force: bool = False) -> str:
 def _lib():
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build_c_oracle())
+        # GPV_ORACLE_LIB: another build of the same two C files (tools/sanitize_host.sh: -fsanitize=address,undefined)
+        _LIB = ctypes.CDLL(os.environ.get("GPV_ORACLE_LIB") or build_c_oracle())
         dp = ctypes.POINTER(ctypes.c_double)
         lp = ctypes.POINTER(ctypes.c_long)
         _LIB.oracle_U_NZentries.restype = ctypes.c_long
