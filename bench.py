@@ -183,27 +183,23 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, ke
     ms, marshal_s, full = marshal_cpu_sample(locs, revNN, revCond, covparms, tau, rows_sample)
     cg0 = cgroup_cpu_state()
     times, nfail = time_oracle_function(ms, logical, repeats, probe)
-    cpu_s_last = time_oracle_function.last_cpu_s
+    cpu_last = time_oracle_function.last_cpu_s / max(times[-1], 1e-9)        # CPU seconds per wall second of the last call
     if keep is not None:
         keep["Lentries"] = ms.L[: b - a]
         keep["n_failed"] = nfail
         keep["rows"] = (a, b)
-    t = float(np.median(times))
-    sets_per_s = (b - a) / t
+    t_all = float(np.median(times))
 
-    def entry(threads, rows, secs, cpu_s):
+    def entry(threads, rows, secs, eff):
         # effective_cores = CPU seconds the call consumed / its wall time: what the host actually granted the threads
-        return {"threads": threads, "rows": rows, "seconds": secs, "sets_per_s": rows / secs,
-                "effective_cores": round(cpu_s / max(times_last(secs), 1e-9), 1)}
-    times_last = lambda secs: secs
-    sw = [entry(logical, b - a, t, cpu_s_last * t / max(times[-1], 1e-9))]
+        return {"threads": threads, "rows": rows, "seconds": secs, "sets_per_s": rows / secs, "effective_cores": round(eff, 1)}
+    sw = [entry(logical, b - a, t_all, cpu_last)]
     if sweep:
-        for th in sorted({physical, 32, 8} - {logical, 1}, reverse=True):
+        for th in sorted({physical, 64, 32, 16, 8} - {logical, 1}, reverse=True):
             if th > logical:
                 continue
             tp, _ = time_oracle_function(ms, th, 2 if th != physical else repeats, probe)
-            cpu_th = time_oracle_function.last_cpu_s * float(np.median(tp)) / max(tp[-1], 1e-9)
-            sw.append(entry(th, b - a, float(np.median(tp)), cpu_th))
+            sw.append(entry(th, b - a, float(np.median(tp)), time_oracle_function.last_cpu_s / max(tp[-1], 1e-9)))
         # one thread: a bounded row sample (full rows, n0 = m + 1) — the whole data set would take ~10-20 s per repeat
         r1 = min(b - a, 60000)
         if r1 == b - a:
@@ -211,23 +207,38 @@ def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, ke
         else:
             m1, _, _ = marshal_cpu_sample(locs, revNN, revCond, covparms, tau, (b - r1, b))
         t1, _ = time_oracle_function(m1, 1, 2, probe)
-        sw.append(entry(1, r1, float(np.median(t1)), time_oracle_function.last_cpu_s * float(np.median(t1)) / max(t1[-1], 1e-9)))
+        sw.append(entry(1, r1, float(np.median(t1)), time_oracle_function.last_cpu_s / max(t1[-1], 1e-9)))
         sw.sort(key=lambda e: e["threads"])
+    # `value` is the FASTEST configuration of the sweep over the whole sample (the strongest baseline this host offers): a
+    # container may show every CPU of the box and still be held to a few of them by a quota, and then all logical CPUs — the
+    # reference's own choice, Ncores = detectCores(logical=TRUE), R/U_sparsity.R:76 — is not the fastest way to run it
+    full_rows = [e for e in sw if e["rows"] == b - a]
+    best = max(full_rows, key=lambda e: e["sets_per_s"])
+    t, sets_per_s, used = best["seconds"], best["sets_per_s"], best["threads"]
     cg1 = cgroup_cpu_state()
     cgroup = dict(cg1)
     if "throttled_usec" in cg0 and "throttled_usec" in cg1:
         cgroup["throttled_usec_during_baseline"] = cg1["throttled_usec"] - cg0["throttled_usec"]
         cgroup["nr_throttled_during_baseline"] = cg1["nr_throttled"] - cg0["nr_throttled"]
+    quota = None
+    try:
+        q, per = cgroup.get("cpu_max", "max 1").split()
+        quota = None if q == "max" else float(q) / float(per)
+    except ValueError:
+        pass
     what = ("oracle/u_nzentries_oracle.c oracle_U_NZentries, the C function ALONE on pre-marshalled arguments (ctypes call "
             f"between two clock reads; marshalling {marshal_s:.2f} s reported apart as marshal_s)")
+    host = (f"{used} threads — the fastest of the thread sweep; the host shows {logical} logical CPUs on {physical} physical cores"
+            + (f", the container's CPU quota is {quota:g} cores (cgroup cpu.max)" if quota else "")
+            + f"; on all {logical} logical CPUs: {t_all:.3f} s")
     if full:
-        sample = (f"all {n} conditioning sets (no extrapolation), {what}, OpenMP schedule(static) on {logical} threads "
-                  f"(all logical CPUs of {physical} physical cores), median of {repeats} = {t:.3f} s")
+        sample = (f"all {n} conditioning sets (no extrapolation), {what}, OpenMP schedule(static) on {host}; median = {t:.3f} s")
     else:
         sample = (f"{b - a} of {n} conditioning sets (rows {a}..{b - 1}, all with n0=m+1), {what}, OpenMP schedule(static) on "
-                  f"{logical} threads (all logical CPUs of {physical} physical cores), median of {repeats} = {t:.3f} s, "
-                  f"EXTRAPOLATED linearly to n")
-    return dict(value=sets_per_s / n, unit="evals/s", cores=logical, physical_cores=physical, kind="port", sample=sample,
+                  f"{host}; median = {t:.3f} s, EXTRAPOLATED linearly to n")
+    return dict(value=sets_per_s / n, unit="evals/s", cores=used, logical_cpus=logical, physical_cores=physical,
+                quota_cores=quota, all_logical={"threads": logical, "seconds": t_all, "sets_per_s": (b - a) / t_all},
+                kind="port", sample=sample,
                 extrapolated=not full, sets_per_s=sets_per_s, seconds=t, marshal_s=marshal_s, thread_sweep=sw,
                 cgroup=cgroup, loadavg=[round(x, 1) for x in os.getloadavg()],
                 timed_callable="ctypes oracle_U_NZentries",
@@ -738,7 +749,7 @@ def main():
     def _measure_gc_off(step, plan, steps, warmup, cw_s, ll):
         # clock warm-up (untimed, before the W warm-up steps): the GPU's power management drops the shader clock within
         # milliseconds of idling and takes ~35 ms of continuous work to bring it back (tools/clock_ramp.py,
-        # profiles/r03_clock_ramp.txt: 1.46 -> 1.26 ms per launch over the first 25 launches at this workload); a timed region of 20
+        # profiles/archive/r03_clock_ramp.txt: 1.46 -> 1.26 ms per launch over the first 25 launches at this workload); a timed region of 20
         # steps behind 5 warm-up steps would measure the ramp, not the rate an optimiser loop sees
         if cw_s > 0:
             t_w = time.perf_counter()

@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(kTabN * 64) gpv_matern_tab_kernel(double nu, i
     // the row format of gpv_bessel.hpp: a_0 .. a_6 doubles, a_7 .. a_10 floats relative to 2^E, E = exponent of a_0
     double *row = rows + (size_t)seg * MaternTab::ROW;
     if (threadIdx.x < MaternTab::NDBL) row[threadIdx.x] = mono[threadIdx.x];
-    if (threadIdx.x < 2) {
+    if (!MaternTab::ALLF64 && threadIdx.x < 2) {
         const double a0 = mono[0];
         const int E = (a0 != 0.0 && isfinite(a0)) ? ilogb(a0) : 0;
         float t[2];

@@ -97,14 +97,28 @@ __host__ __device__ inline double matern_general(const double s, const double no
 // a_0 (two per double slot, low word first).  a_k falls like 17^-k, so the tail a_7 u^7 + .. is below 2.4e-9 |a_0| and its
 // float rounding (6e-8) below 1.5e-16; it is evaluated in FP32 as well and joins the FP64 Horner chain through one
 // conversion and one multiplication by 2^E (the exponent bits of a_0).
+// Round 6, GPV_MT_F64 = 1: SIXTEEN segments per octave at degree 8, all nine coefficients doubles — the same 72 bytes per
+// row (what a pair pays in LDS bandwidth), no FP32 tail: 8 FMAs where the mixed row costs 6 FMAs + conversion, three FP32
+// FMAs, the 2^E extraction, conversion back and a multiplication.  The nearest singularity (s = 0) is at least 33 half-widths
+// from a segment's centre: interpolation error ~ 66^-9 = 4e-17 relative, coefficients decay like 33^-k.  A window of 8
+// octaves is then 128 rows = 9.2 KB: it fits where ONE eight-wavefront workgroup per CU shares it (gpv_sets_kernel.hpp, wpb).
+#ifndef GPV_MT_F64
+#define GPV_MT_F64 0
+#endif
 struct MaternTab {
+#if GPV_MT_F64
+    static constexpr int DEG = 8, NDBL = 9, ROW = 9, LSPO = 4, SPO = 1 << LSPO;
+#else
     static constexpr int DEG = 10, NDBL = 7, ROW = 9, LSPO = 3, SPO = 1 << LSPO;   // degree, double coefficients, doubles per row, segments per octave
+#endif
+    static constexpr bool ALLF64 = NDBL == DEG + 1;
     static constexpr int FOLD_EXP = 2;                                      // segments with binary exponent < 2 carry exp(-s)
 };
 // the host side of the format: monomial coefficients a[0..DEG] (already scaled) -> one row
 inline void matern_tab_pack_row(const double *a, double *row)
 {
     for (int j = 0; j < MaternTab::NDBL; ++j) row[j] = a[j];
+    if (MaternTab::ALLF64) return;
     int E = 0;
     if (a[0] != 0.0 && std::isfinite(a[0])) (void)std::frexp(a[0], &E), E -= 1;       // a_0 = m 2^E, 1 <= |m| < 2
     float t[4];
@@ -128,6 +142,12 @@ __device__ __forceinline__ double matern_tab_poly(const double (&r)[MaternTab::R
     const unsigned lo = (unsigned)__double2loint(s), hi = (unsigned)__double2hiint(s);
     const unsigned ghi = (__builtin_amdgcn_alignbit(hi, lo, 32 - MaternTab::LSPO) & 0x000FFFFFu) | 0x3FF00000u;
     const double u = __builtin_fma(__hiloint2double((int)ghi, (int)(lo << MaternTab::LSPO)), 2.0, -3.0);
+    if constexpr (MaternTab::ALLF64) {
+        double p = r[MaternTab::DEG];
+#pragma unroll
+        for (int k = MaternTab::DEG - 1; k >= 0; --k) p = __builtin_fma(p, u, r[k]);
+        return p;
+    }
     const float uf = (float)u;
     float t = __builtin_fmaf(__int_as_float(__double2hiint(r[8])), uf, __int_as_float(__double2loint(r[8])));
     t = __builtin_fmaf(t, uf, __int_as_float(__double2hiint(r[7])));

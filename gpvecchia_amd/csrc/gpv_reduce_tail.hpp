@@ -23,7 +23,7 @@ __device__ __forceinline__ void publish_seq(unsigned long long *cell, unsigned l
 }
 
 // Call from every thread of the workgroup; threads 0..kNSums-1 (wave 0) hold this workgroup's partial sums in `mine`.
-// NT = threads per workgroup (a multiple of 64, at most 256).  s_part (NT doubles) and s_last_p (one int) are LDS the
+// NT = threads per workgroup (a multiple of 64, at most 512).  s_part (NT doubles) and s_last_p (one int) are LDS the
 // workgroup no longer uses (the caller has passed a workgroup barrier since their last use): the kernels run at the edge of
 // the 160 KiB of a CU and a declaration of their own would cost a resident workgroup.
 // AP: `const SetArgs *` or a pointer to the arguments in the kernarg segment (kargs_now() of gpv_sets_kernel.hpp): the fields are
@@ -32,7 +32,7 @@ template <int NT, class AP>
 __device__ __forceinline__ void reduce_tail(AP Ap, double mine, double *s_part, int *s_last_p)
 {
     const auto &A = *Ap;
-    static_assert(NT % 64 == 0 && NT <= 256, "workgroup size");
+    static_assert(NT % 64 == 0 && NT <= 512, "workgroup size");
     if (threadIdx.x < kNSums) A.block_sums[(int64_t)blockIdx.x * kNSums + threadIdx.x] = mine;
     if (threadIdx.x < 64) {                              // the wave that stored
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

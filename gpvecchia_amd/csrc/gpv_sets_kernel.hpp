@@ -277,8 +277,29 @@ struct SetsLds {
 };
 
 // waves per workgroup: 4 when two 4-wave workgroups fit the 160 KiB of LDS of a CU, else single-wave workgroups
+// General nu with the all-FP64 table rows (GPV_MT_F64): ONE eight-wave workgroup per CU where that leaves the shared window of
+// the Matern table more rows than two four-wave workgroups with a window each (P = 31: 128 rows = 8 octaves against 64 = 4)
+#ifndef GPV_GEN_W8
+#define GPV_GEN_W8 GPV_MT_F64
+#endif
 template <int P, int D, int COV>
-constexpr int wpb() { return (sizeof(SetsLds<P, D, COV>) * 8 <= 163840) ? 4 : 1; }
+constexpr long mt_rows_for(int w, int bpc)
+{
+    const long left = 163840 / bpc - (long)sizeof(SetsLds<P, D, COV>) * w - 64;
+    long rows = left / (MaternTab::ROW * 8);
+    rows = rows > 10 * MaternTab::SPO ? 10 * MaternTab::SPO : rows;
+    rows &= ~(long)(MaternTab::SPO - 1);            // whole octaves
+    return rows < 2 * MaternTab::SPO ? 0 : rows;
+}
+template <int P, int D, int COV>
+constexpr int wpb()
+{
+    if (sizeof(SetsLds<P, D, COV>) * 8 > 163840) return 1;
+    if (GPV_GEN_W8 != 0 && COV == COV_MATERN_GEN && D != 0 && Geo<P>::MINW == 2 &&
+        mt_rows_for<P, D, COV>(8, 1) > mt_rows_for<P, D, COV>(4, 2))
+        return 8;
+    return 4;
+}
 // resident workgroups per CU (LDS-limited, at most 2 waves per SIMD are needed)
 template <int P, int D, int COV>
 constexpr int blocks_per_cu()
@@ -297,12 +318,7 @@ template <int P, int D, int COV>
 constexpr int mt_window_rows()
 {
     if (COV != COV_MATERN_GEN || D == 0) return 0;
-    const int w = wpb<P, D, COV>();
-    const long left = 163840 / blocks_per_cu<P, D, COV>() - (long)sizeof(SetsLds<P, D, COV>) * w - 64;
-    long rows = left / (kMtRowLds * 8);
-    rows = rows > 10 * MaternTab::SPO ? 10 * MaternTab::SPO : rows;
-    rows &= ~(long)(MaternTab::SPO - 1);            // whole octaves
-    return rows < 2 * MaternTab::SPO ? 0 : (int)rows;
+    return (int)mt_rows_for<P, D, COV>(wpb<P, D, COV>(), blocks_per_cu<P, D, COV>());
 }
 
 // Lanes of one wavefront exchange data through LDS.  The hardware executes a wave's LDS
@@ -557,7 +573,7 @@ __device__ __forceinline__ double matern_general_seg(const double *mt, int mt_ba
 // Two stages, so that the rounds can fetch the rows of round s + 1 before they evaluate round s (cov_rounds_fast):
 //   matern_table_fetch: the row of the lane's segment into r[] -- from the LDS window when the segment sits in it, else from
 //     the table in global memory (a few lanes of a wave at most: with every lane sent to global memory as soon as one of the
-//     64 fell outside, 44 % of the rounds gathered 64 x 96 bytes through the texture path; profiles/r03_nu11_pmc_summary.json,
+//     64 fell outside, 44 % of the rounds gathered 64 x 96 bytes through the texture path; profiles/archive/r03_nu11_pmc_summary.json,
 //     22.6 M VMEM reads).  Every lane reads LDS (an outside lane row 0), the global row then overwrites in place.
 //   matern_table_value: the polynomial, and exp(-s) where the row does not carry it.
 template <int MTW>
@@ -1136,6 +1152,12 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
             } else
 #pragma unroll
             for (int s = 1; s <= H; ++s) {
+#ifdef GPV_COV_ROUNDS_KEEP
+                // TIMING EXPERIMENT ONLY, RESULTS WRONG (tagged developer builds): the rounds beyond
+                // the first GPV_COV_ROUNDS_KEEP are not evaluated -- the ceiling of what evaluating shared point pairs once
+                // could save if finding and scattering them cost nothing
+                if (s > GPV_COV_ROUNDS_KEEP) continue;
+#endif
                 double xc[RPL][DD];
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
@@ -1547,7 +1569,9 @@ hipError_t launch_sets_PDC(const SetArgs &a_in, int cus, int *grid_out, hipStrea
     static const char *shares_env = dev_getenv("GPV_SHARES");            // developer aid: "3,2"
     const int64_t slots = (int64_t)cus * blocks_per_cu<P, D, COV>() * W;
     const bool paired = !no_uneven && W == 4 && blocks_per_cu<P, D, COV>() == 2 && (cus % 8) == 0 && tasks >= 3 * slots;
-    const int mult = mult_env > 0 ? mult_env : (paired ? 1 : (tasks < 48 * slots ? 1 : 4));
+    //   * one eight-wave workgroup per CU (general nu with the all-FP64 table rows): one workgroup per slot, equal shares
+    //     (both wavefronts of a SIMD belong to the same workgroup and were dispatched together).
+    const int mult = mult_env > 0 ? mult_env : ((paired || W == 8) ? 1 : (tasks < 48 * slots ? 1 : 4));
     int64_t cap = (int64_t)cus * blocks_per_cu<P, D, COV>() * mult;    // grid-stride beyond
     if (cap > kMaxGrid) cap = kMaxGrid;
     const int grid = (int)(need < cap ? (need < 1 ? 1 : need) : cap);

@@ -67,7 +67,8 @@ def test_cpu_baseline_times_the_c_function_alone(monkeypatch):
     assert np.array_equal(kept["Lentries"], want) and kept["rows"] == (0, n)
     assert res["timed_callable"] == "ctypes oracle_U_NZentries" and res["marshal_s"] > 0 and res["seconds"] > 0
     th = [e["threads"] for e in res["thread_sweep"]]
-    assert th == sorted(th) and th[0] == 1 and th[-1] == res["cores"] and all(e["sets_per_s"] > 0 for e in res["thread_sweep"])
+    assert th == sorted(th) and th[0] == 1 and th[-1] == res["logical_cpus"] and all(e["sets_per_s"] > 0 for e in res["thread_sweep"])
+    assert res["cores"] in th and res["sets_per_s"] == max(e["sets_per_s"] for e in res["thread_sweep"] if e["rows"] == n)
     # a row sample (the extrapolated form) computes the same rows
     kept2 = {}
     res2 = bench.cpu_baseline(locs, revNN, revCond, [1., .1, 1.5], .1, (n - 500, n), repeats=1, keep=kept2, sweep=False)
