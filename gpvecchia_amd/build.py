@@ -106,6 +106,59 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
     return LIB
 
 
+def dpp_hazards(obj: str):
+    """Verification of a built set-kernel object: the sweeps read other lanes' registers through DPP operands of INLINE-ASM
+    instructions (v_fmac_f64_dpp ... row_newbcast), which hipcc's hazard recogniser does not look into -- a VALU write of a VGPR
+    needs two wait states before a DPP read of it, and under register pressure the compiler fetches parked values back from
+    AGPRs (v_accvgpr_read) right in front of their use.  Disassembles the gfx950 code object inside `obj` and returns
+    (DPP instructions, hazards): reads whose source register was written by one of the two preceding instructions (s_nop N
+    counts as N + 1 wait states).  (None, None) for an object without device code (the per-P dispatch units)."""
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "x.fat"), os.path.join(td, "x.co")
+        subprocess.check_call([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat])
+        r = subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                            f"--targets=hipv4-amdgcn-amd-amdhsa--{ARCH}", f"--output={co}"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return None, None
+        dis = subprocess.run([f"{llvm}/llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+
+    def regs(tok):
+        m = re.match(r"v\[(\d+):(\d+)\]", tok)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.match(r"v(\d+)$", tok)
+        return {int(m.group(1))} if m else set()
+    ndpp = bad = 0
+    for blk in re.split(r"\n(?=[0-9a-f]+ <)", dis):
+        if "gpv_sets_kernel" not in blk.split("\n", 1)[0]:
+            continue
+        hist = []                                     # (VGPRs written, wait states the instruction provides)
+        for line in blk.split("\n")[1:]:
+            t = line.strip().split("//")[0].strip()
+            if not t or t.endswith(":"):
+                continue
+            op, _, rest = t.partition(" ")
+            ops = [o.strip() for o in rest.split(",")]
+            if op == "s_nop":
+                hist.append((set(), int(ops[0], 0) + 1))
+                continue
+            if "row_newbcast" in t or "row_bcast" in t or "_dpp" in op:
+                ndpp += 1
+                src = regs(ops[1].lstrip("-").split()[0]) if len(ops) > 1 else set()
+                ws = 0
+                for w, states in reversed(hist[-4:]):
+                    if ws >= 2:
+                        break
+                    if w & src:
+                        bad += 1
+                        break
+                    ws += states
+            hist.append((regs(ops[0].split()[0]) if op.startswith("v_") and ops and ops[0] else set(), 1))
+    return ndpp, bad
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
@@ -113,6 +166,17 @@ if __name__ == "__main__":
     ap.add_argument("--tag", default="")
     ap.add_argument("--flags", default="", help="extra hipcc flags for the kernel TUs, space separated")
     ap.add_argument("--plist", default="", help="tagged builds: compile these row lengths only, e.g. 21,31,61")
+    ap.add_argument("--check-dpp", action="store_true", help="scan the built set-kernel objects for DPP read hazards (dpp_hazards)")
     a = ap.parse_args()
     print(build(a.force, a.jobs, verbose=True, tag=a.tag, extra_flags=a.flags.split(),
                 only=[int(x) for x in a.plist.split(",") if x] or None))
+    if a.check_dpp:
+        import glob
+        tot = 0
+        for o in sorted(glob.glob(os.path.join(BUILD, "sets_p*.o"))):
+            nd, bad = dpp_hazards(o)
+            if nd is not None:
+                tot += bad
+                print(f"  {os.path.basename(o)}: {nd} DPP instructions, {bad} hazard(s)")
+        print("DPP hazards:", tot)
+        sys.exit(1 if tot else 0)

@@ -101,6 +101,9 @@
 #ifndef GPV_OPT_KARGS
 #define GPV_OPT_KARGS 1       // arguments used only in a task's epilogue / after the task loop are read from the kernarg segment THERE
 #endif                        // (scalar loads) instead of living in SGPRs through the loop: the compiler spilled them to VGPR lanes
+#ifndef GPV_OPT_PIVROW
+#define GPV_OPT_PIVROW 1      // 16-lane DPP sweep: the pivot row's elements are read from the pivot row (lane j % 16), not from column
+#endif                        // j of the other rows "by symmetry": consistent elimination, residuals of 1e-16 instead of 1e-13 (round 6)
 #ifndef GPV_OPT_RCP3
 #define GPV_OPT_RCP3 1        // pivot reciprocal: one third-order step on the v_rcp_f64 seed (3 FMAs) instead of two Newton steps (4)
 #endif
@@ -117,8 +120,9 @@ namespace gpv {
 #define GPV_DPP 1
 #endif
 #ifndef GPV_DPP_MINP
-#define GPV_DPP_MINP 12        // P = 16, 21: -14 %, -5 % against the LDS path; P = 11: +8 % (12 lanes x 5 sets per wave win)
-#endif
+#define GPV_DPP_MINP 11        // P = 16, 21: -14 %, -5 % against the LDS path.  P = 11: the LDS path with its 12 lanes x 5 sets per wave was
+#endif                         // 8 % faster while it exchanged COLUMN j; publishing the pivot ROW (round 6, GPV_OPT_PIVROW: consistent
+                               // elimination) costs it 26 %, and the DPP geometry, which reads the pivot row for free, wins at P = 11 too
 #ifndef GPV_DPP_MAXP
 #define GPV_DPP_MAXP 48        // 3 rows per lane; 4 rows of > 48 columns do not fit the 512 registers
 #endif
@@ -366,6 +370,17 @@ __device__ __forceinline__ double rcp_pivot_bounded(double x)
     r = __builtin_fma(r, e, r);
     return r;
 #endif
+}
+
+// 1/sqrt(x) for a pivot of the row-pair DPP sweep (GPV_OPT_PIVROW): v_rsq_f64 seed (~2^-23) + one third-order step,
+// y0 (1 + e/2 + 3 e^2/8) with e = 1 - x y0^2: the e^3 term is below 2^-68.  x <= 0 or NaN gives NaN (0: Inf * 0), so that the
+// square of the result, the row's recorded pivot reciprocal, is > 0 exactly when the pivot is -- what the failure test reads.
+__device__ __forceinline__ double rsqrt_pivot(double x)
+{
+    const double y0 = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-(x * y0), y0, 1.0);
+    const double c = __builtin_fma(e, 0.375, 0.5);
+    return __builtin_fma(y0 * e, c, y0);
 }
 
 // sqrt(x), x > 0 normal: v_rsq_f64 seed + one Goldschmidt step on g + one residual step
@@ -1288,16 +1303,43 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                     }
                     pj = dpp_row_bcast<j % 16>((j % 32) < 16 ? ylo[qj] : yhi[qj], ylo[0], yhi[0], ylo[RPL - 1], yhi[RPL - 1]);
                 }
-                const double rinv = rcp_pivot_bounded(pj);
+                // Row-pair geometry (LPS = 32), GPV_OPT_PIVROW: the pivot row cannot be read out of its own lane (it would take a
+                // row-pair swap per ELEMENT), so column j stands in for it as before -- but the update is made bit-for-bit
+                // symmetric: both factors of a_rc -= (a_rj / sqrt p)(a_cj / sqrt p) carry the SAME rounding, the product commutes,
+                // (r, c) and (c, r) receive identical bits, and column j IS the pivot row, not only equal to it in exact arithmetic
+                // (see the 16-lane branch below for what the difference costs).  Price: v_rsq instead of v_rcp (+2), the
+                // reciprocal as a square (+1), the partner rows' column entries scaled like the own ones (2 per live slot).
+                constexpr bool SYMSCALE = GPV_OPT_PIVROW != 0 && LPS == 32;
+                double rinv;
+                double rs = 0.0;
+                if constexpr (SYMSCALE) {
+                    rs = rsqrt_pivot(pj);
+                    rinv = rs * rs;
+                } else {
+                    rinv = rcp_pivot_bounded(pj);
+                }
                 // row slots below qj hold only rows whose own pivot step is over.  Gauss-Jordan would go on reducing them
                 // (their last column is the solution); with FREEZE they rest from here on and are completed after the sweep
                 constexpr int Q0 = (GPV_OPT_FREEZE != 0) ? qj : 0;
                 double nw[RPL];
 #if GPV_OPT_EXECFIX
 #pragma unroll
-                for (int q = Q0; q < RPL; ++q) nw[q] = a[q][j] * -rinv;
+                for (int q = Q0; q < RPL; ++q) nw[q] = a[q][j] * (SYMSCALE ? -rs : -rinv);
+                if constexpr (SYMSCALE) {
+#pragma unroll
+                    for (int q = qj; q < RPL; ++q) {
+                        ylo[q] *= rs;
+                        yhi[q] *= rs;
+                        dpp_settle(ylo[q], yhi[q]);                     // VALU write -> DPP read: two wait states
+                    }
+                }
+                if constexpr (LPS == 16 && GPV_OPT_PIVROW != 0) {                 // (the first two DPP sources of this pivot: see below)
+                    if constexpr (j + 1 < P) asm volatile("" : "+v"(a[qj][j + 1]));
+                    if constexpr (j + 2 < P) asm volatile("" : "+v"(a[qj][j + 2]));
+                }
                 pivot_lane_fix<LPS, j % LPS>(nw[qj], prinv[qj], rinv);
 #else
+                static_assert(!SYMSCALE, "the symmetric scaling is written for the EXEC-masked pivot fix");
                 const bool isp = (i == j % LPS);
                 prinv[qj] = isp ? rinv : prinv[qj];
 #pragma unroll
@@ -1308,10 +1350,31 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #endif
                 static_for<j + 1, P>([&](auto cc) __attribute__((always_inline)) {
                     constexpr int c = decltype(cc)::value;
+                    if constexpr (LPS == 16 && GPV_OPT_PIVROW != 0) {
+                        // element c of the pivot row is read from the pivot row ITSELF: register a[qj][c] of lane j % 16.  Round 6:
+                        // until then it was read as a[c / 16][j] of lane c % 16 -- column j of the current matrix, which equals the
+                        // pivot row in exact arithmetic only.  The two differ by the rounding asymmetry of the updates (of the order
+                        // of eps |S|, i.e. eps cond(S) relative to the cancelled Schur complements), and eliminating x_j from the
+                        // other equations with one while equation j keeps the other leaves the system inconsistent by that much:
+                        // the rows came out as ACCURATE as LAPACK's (forward error) but their residuals S x - e / d were ~1e-13
+                        // where dpotf2 + dtrsv leave 1e-16, and a posterior mean built from them was 10-25 x less accurate than the
+                        // reference's on ill-conditioned plans (tools/accuracy_rows_probe.py).  Same instruction
+                        // count.  The slot of the pivot row goes last, so that no DPP read follows a write of its register.
+                        // (the DPP source of column c + 2 is pinned to a VGPR HERE, two FMAs ahead of its read: under register
+                        //  pressure -- three rows per lane at P = 41 -- hipcc parks matrix registers in AGPRs and fetches them back
+                        //  with v_accvgpr_read right in front of their use, a VALU write the inline-asm DPP read would not wait
+                        //  for; tools/dpp_hazard_scan.py checks every built object for exactly that)
+                        if constexpr (c + 2 < P) asm volatile("" : "+v"(a[qj][c + 2]));
 #pragma unroll
-                    for (int q = Q0; q < RPL; ++q) {
-                        if constexpr (LPS == 16) dpp_fmac<c % 16>(a[q][c], a[c / 16][j], nw[q]);
-                        else dpp_fmac<c % 16>(a[q][c], (c % 32) < 16 ? ylo[c / 32] : yhi[c / 32], nw[q]);
+                        for (int q = Q0; q < RPL; ++q)
+                            if (q != qj) dpp_fmac<j % 16>(a[q][c], a[qj][c], nw[q]);
+                        dpp_fmac<j % 16>(a[qj][c], a[qj][c], nw[qj]);
+                    } else {
+#pragma unroll
+                        for (int q = Q0; q < RPL; ++q) {
+                            if constexpr (LPS == 16) dpp_fmac<c % 16>(a[q][c], a[c / 16][j], nw[q]);
+                            else dpp_fmac<c % 16>(a[q][c], (c % 32) < 16 ? ylo[c / 32] : yhi[c / 32], nw[q]);
+                        }
                     }
                 });
             });
@@ -1353,8 +1416,21 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
 #pragma unroll
             for (int j = 0; j < P - 1; ++j) {
                 double *cb = L.col[j & 1][sub];
+#if GPV_OPT_PIVROW
+                // the pivot row ITSELF goes to the exchange buffer: its owner publishes elements j .. P-1 of its row (one lane per
+                // set stores, P - j values).  Until round 6 every lane published its entry of COLUMN j instead -- the pivot row by
+                // symmetry, in exact arithmetic only (see the 16-lane DPP branch above for what the difference costs)
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    if (wslot[q] == j) {
+#pragma unroll
+                        for (int c = j; c < P; ++c) cb[c] = a[q][c];
+                    }
+                }
+#else
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) cb[wslot[q]] = a[q][j];    // column j of the current matrix == pivot row by symmetry
+#endif
                 wave_sync();
                 constexpr int CH = (P <= 32) ? GPV_CHUNK : 4;   // wide rows: keep the burst small, a[] already needs 2P VGPRs
                 double t[2][CH];

@@ -369,3 +369,23 @@ def test_hash_bytes_and_index_array_fingerprint():
     assert f1 != f2 and f1 == A._fingerprint(a) and A._fingerprint(np.asfortranarray(a)) != f1   # (strides are part of it)
     nn_r, cd_r = A._r_layout_cached(np.zeros((0, 5), np.int32), np.zeros((0, 5), np.int8))
     assert nn_r.shape == (0, 5) and cd_r.shape == (0, 5)
+
+
+def test_built_set_kernels_have_no_dpp_read_hazard():
+    """The sweeps' DPP operands sit in inline asm, which hipcc's hazard recogniser does not see: a VGPR written by one of the
+    two preceding instructions (a value fetched back from an AGPR under register pressure, say) must never be a DPP source.
+    gpvecchia_amd.build.dpp_hazards disassembles every built set-kernel object; round 6 found two such reads in the P = 41,
+    generic-dimension, general-nu instantiation while the pivot row's read was being moved, and pinned the sources ahead."""
+    import glob
+    from gpvecchia_amd import build as B
+    objs = sorted(glob.glob(os.path.join(B.CSRC, "build", "sets_p*.o")))
+    if not objs:
+        pytest.skip("no object files in this tree (library built elsewhere)")
+    seen = 0
+    for o in objs:
+        nd, bad = B.dpp_hazards(o)
+        if nd is None:
+            continue
+        seen += nd
+        assert bad == 0, (os.path.basename(o), nd, bad)
+    assert seen > 10_000                                             # the DPP sweeps were really looked at

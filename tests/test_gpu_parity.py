@@ -502,6 +502,53 @@ def test_literal_dropin_plan_cache():
     _lib.lib().gpv_plan_cache_clear()
 
 
+@pytest.mark.parametrize("m", [3, 7, 10, 13, 30, 47, 60, 70])
+def test_rows_are_backward_stable_like_lapack(m):
+    """arma::chol + arma::solve (src/U_NZentries.cpp:61-62) are dpotrf + a triangular solve: backward stable, the computed row
+    x satisfies S x = e_last / d with a residual of eps |S| |x| however ill-conditioned S is.  The kernel's elimination must be
+    as good: a posterior mean or a Newton iteration built on rows that are merely as ACCURATE as LAPACK's (forward error) but
+    have residuals of 1e-13 is 10-25 x less accurate than the reference's (round 6: the sweeps read the pivot row as "column j
+    by symmetry" until then; tools/accuracy_rows_probe.py).  Every sweep geometry: LDS exchange (m + 1 = 4, 8), one 16-lane DPP
+    row per set (11, 16, 31, 48), a row pair (61), the workgroup-per-set kernel (71).  All-latent sets of a smooth Matern 2.5
+    covariance with a long range: cond(S) up to 1e12; residuals measured in x87 extended precision."""
+    G = _need_gpu()
+    from oracle import r_side as R
+    rng = np.random.default_rng(50 + m)
+    n = 1200
+    locs = rng.random((n, 2))
+    cp = [0.97, 0.2, 2.5]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        va = R.vecchia_specify(locs, m, ordering="none", cond_yz="y")
+    prep, lo = va["U_prep"], va["locsord"]
+    tau = np.full(n, 1e-6)
+    out = G.U_NZentries(1, n, lo, prep["revNNarray"], prep["revCond"], tau, tau, "matern", cp)
+    ref = R.U_NZentries(1, n, lo, np.nan_to_num(prep["revNNarray"]), np.nan_to_num(prep["revCond"]), tau, tau, "matern", cp)
+    assert out["n_failed"] == 0 and ref["n_failed"] == 0
+    ld = np.longdouble
+    lx, s5 = lo.astype(ld), np.sqrt(ld(5))
+
+    def residuals(L):
+        res = np.empty(n)
+        for k in range(n):
+            ok = ~np.isnan(prep["revNNarray"][k])
+            J = prep["revNNarray"][k, ok].astype(int) - 1
+            P_ = lx[J]
+            t = s5 * np.sqrt(((P_[:, None, :] - P_[None, :, :]) ** 2).sum(axis=2)) / ld(cp[1])
+            S = ld(cp[0]) * np.exp(-t) * (1 + t + t * t / 3)                      # src/Matern.cpp:68 in extended precision
+            S[np.diag_indices(len(J))] = ld(cp[0])                                # all latent: no nugget (src/U_NZentries.cpp:47)
+            x = L[k, :len(J)].astype(ld)
+            rhs = np.zeros(len(J), dtype=ld)
+            rhs[-1] = 1 / x[-1]                                                   # R x = e_last, R^T R = S  =>  S x = e_last / x_last
+            res[k] = float(np.abs(S @ x - rhs).max() / (np.abs(S) @ np.abs(x)).max())
+        return res
+    rh, ro = residuals(out["Lentries"]), residuals(ref["Lentries"])
+    assert np.median(ro) < 5e-16 and ro.max() < 5e-15                             # the oracle is dpotf2 + dtrsv
+    assert np.median(rh) < 5e-15, (m, np.median(rh), rh.max())                    # (the column-by-symmetry sweeps: 5e-14 .. 7e-13)
+    assert rh.max() < 1e-12, (m, np.median(rh), rh.max())                         # (they reached 1e-10 .. 4e-9)
+
+
 def test_literal_dropin_failure_behind_a_speculative_evaluation_leaves_no_stale_rows():
     """gpv_U_NZentries evaluates a cached plan of the right SHAPE at once and hashes the arrays meanwhile: its U
     entries are in the caller's buffer before the hash has spoken.  When the hash then misses and the rebuild fails (here: an
