@@ -20,9 +20,12 @@
 //     b = S11^{-1} s_l and v = s_ll - s_l^T b (Schur complement) one has
 //     x = [-b ; 1] / sqrt(v).  b and v come from a Gauss-Jordan sweep over the
 //     first P-1 pivots in which EVERY lane keeps working (rows above the pivot
-//     are reduced too).  The pivot-row element each FMA needs sits, by symmetry, in a register of another lane of
-//     the set: the DPP geometries read it there with v_fmac_f64_dpp ... row_newbcast (no LDS, no wait in the sweep),
-//     the small geometries exchange the pivot row through a 2-slot LDS buffer with broadcast reads.  The pivots are
+//     are reduced too).  The pivot-row element each FMA needs sits in a register of the lane that owns the pivot row:
+//     the 16-lane DPP geometry reads it there with v_fmac_f64_dpp ... row_newbcast (no LDS, no wait in the sweep), the
+//     small geometries exchange the pivot row through a 2-slot LDS buffer with broadcast reads; the row-pair geometry
+//     reads column j instead and keeps the trailing matrix symmetric BIT FOR BIT, so that column j is the pivot row.
+//     (Round 6: the pivot ROW, not "column j, which equals it by symmetry": equal in exact arithmetic only, and an
+//     elimination that mixes the two leaves residuals 1000 x LAPACK's; GPV_OPT_PIVROW.)  The pivots are
 //     exactly the Schur complements d_j^2 whose positivity decides "Cholesky failed" in the reference (:60-66);
 //   * a spare row slot (P odd, or a spare lane) carries the DATA as one more row of the
 //     sweep: after the last pivot it holds -mu_k = -sum_j b_j z_j, the conditional mean needed
@@ -110,12 +113,13 @@
 
 namespace gpv {
 
-// DPP geometries.  16 lanes (22 <= P <= 48): a set occupies exactly one 16-lane DPP row (4 sets per wave), lane i of the
+// DPP geometries.  16 lanes (11 <= P <= 48): a set occupies exactly one 16-lane DPP row (4 sets per wave), lane i of the
 // row owns the rows i, i+16, i+32 of the block.  The wave-uniform-per-set operand of the elimination sweep (pivot-row
-// element c = register a[c/16][j] of lane c%16, by symmetry) is then read straight out of the other lane's register by
-// the 64-bit DPP control row_newbcast:(c%16) of v_fmac_f64_dpp: no LDS write, read or s_waitcnt in the sweep.
+// element c = register a[j/16][c] of lane j%16, the lane that owns pivot row j) is read straight out of that lane's register
+// by the 64-bit DPP control row_newbcast:(j%16) of v_fmac_f64_dpp: no LDS write, read or s_waitcnt in the sweep.
 // 32 lanes (49 <= P <= 64): a set is a PAIR of DPP rows (2 sets per wave), lane i owns rows i and i+32; per pivot one
-// v_permlane16_swap per 32-bit half leaves column j of both DPP rows in both of them, then the same DPP FMAs.
+// v_permlane16_swap per 32-bit half leaves column j of both DPP rows in both of them (scaled by 1/sqrt(pivot): the updates
+// are then products of two equally rounded factors, bit-symmetric, and column j IS the pivot row), then the same DPP FMAs.
 #ifndef GPV_DPP
 #define GPV_DPP 1
 #endif
@@ -1281,8 +1285,8 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
         double vlast;                                  // Schur complement of the point itself (row P-1)
         double negmu_z = 0.0;                          // data row after the sweep: -mu_k (ZROW geometries)
         if constexpr (G::DPP) {
-            // the pivot row never leaves the registers: element c of pivot row j is a[c/16][j] of lane c%16 (column j
-            // of the current matrix == pivot row by symmetry), fetched by the DPP row broadcast of each FMA
+            // the pivot row never leaves the registers: element c of pivot row j is a[j/16][c] of lane j%16, fetched by the DPP
+            // row broadcast of each FMA (row pairs: column j of the bit-symmetric current matrix, see below)
             static_for<0, P - 1>([&](auto jc) __attribute__((always_inline)) {
                 constexpr int j = decltype(jc)::value;
                 constexpr int qj = j / LPS;                                 // the slot that holds pivot row j (in lane j % LPS)
