@@ -33,7 +33,9 @@ for seed in range(lo, hi):
     cp = [float(0.5 + rng.random()), float(0.03 + 0.15 * rng.random()), nu]
     tau = 0.05 + 0.3 * rng.random(n) if rng.random() < 0.6 else float(0.05 + 0.3 * rng.random())
     cond = str(rng.choice(["SGV", "SGVT", "zy", "y"]))
-    op = str(rng.choice(["obspred", "general"]))
+    # the reference implements 'zy' for ordering.pred = 'obspred' only (R/vecchia_specify.R:212) and SGV / SGVT with a general
+    # ordering condition on observations of unobserved locations (U_sparsity stops): the valid combinations
+    op = str(rng.choice(["obspred", "general"])) if cond == "y" else "obspred"
     desc = dict(n=n, n_p=n_p, m=m, d=d, cond=cond, ordering_pred=op, nu=nu)
     try:
         with warnings.catch_warnings():
