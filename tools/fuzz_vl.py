@@ -66,9 +66,14 @@ for seed in range(lo, hi):
             # without missing data); the HIP loop passes on err_hip <= max(4 err_oracle, 1e-8), the rule of the tests; a step
             # count that differs by one passes when the oracle's own trace crossed the threshold within a factor of two
             verdict = "UNADJUDICATED"
-            if not np.isnan(z).any():
+            if True:
                 pmv = np.zeros(n) if pm is None else pm
-                ex = R.posterior_extended(ref["t"] - pmv, vb, cp, ref["D"])
+                # the step's prediction problem as vecchia_prediction sees it (R/vecchia_laplace_NR.R:103-113): pseudo-data with NA and
+                # pseudo-variances with Inf at the missing observations, through removeNAs (R/vecchia_likelihood.R:45-58)
+                nug_full = np.full(n, np.inf)
+                nug_full[~np.isnan(z)] = ref["D"]
+                zz, nn = R.removeNAs(ref["t"] - pmv, nug_full)
+                ex = R.posterior_extended(zz, vb, cp, nn)
                 mu_x = np.empty(n)
                 mu_x[va["ord"] - 1] = ex["mu_ord"]
                 mu_x = mu_x + pmv
