@@ -8,7 +8,7 @@
 // How (not a translation of the reference):
 //   * one wavefront handles SPW = floor(64/LPS) conditioning sets at once; a set is spread over LPS lanes and lane
 //     (sub, i) owns the rows i, i+LPS, .. of the symmetric block in 2*RPL*P VGPRs.  Geometries (Geo<P>): one 16-lane
-//     DPP row per set for 12 <= P <= 48, a pair of DPP rows for 49 <= P <= 64, P (+1) lanes with one row each below;
+//     DPP row per set for 11 <= P <= 48, a pair of DPP rows for 49 <= P <= 64, P (+1) lanes with one row each below;
 //   * neighbour indices / cond flags are read as one contiguous segment per set,
 //     coordinates and datum gathered as one 32-byte record per neighbour and staged in LDS;
 //   * the P(P-1)/2 distinct covariances are evaluated once each with a circulant
