@@ -627,7 +627,7 @@ __global__ void __launch_bounds__(64 * kTopWaves) gpv_posterior_top_kernel(const
 }
 
 // ---- the dense top block, two-block form: K up to 128 --------------------------------------------------------------------
-// The ~21 highest levels of the schedule hold 1-5 columns each (n = 1e6, m = 30, maxmin: profiles/r04_sgv_levels.txt), 6-7 us
+// The ~21 highest levels of the schedule hold 1-5 columns each (n = 1e6, m = 30, maxmin: profiles/archive/r04_sgv_levels.txt), 6-7 us
 // apiece as launches.  The plan moves them into the block (gpv_api.hip), which then has up to 128 columns: A = the first 64
 // columns of the ordering, B = the others, and
 //     [ S_AA  S_AB ]   [ R_AA  R_AB ] [ R_AA  R_AB ]^T

@@ -126,7 +126,7 @@ def test_posterior_pass_random_plans_against_the_oracle(seed):
     createU -> U2V -> vecchia_likelihood_U / vecchia_mean (R/vecchia_prediction.R:62-83,118-126, R/vecchia_likelihood.R:85-90)
     and, as a second opinion, the product's own host route (SuperLU).  A mean beyond the flat 1e-8 is adjudicated in
     extended precision like everywhere else.  tools/fuzz_posterior.py: 1000 seeds against the host route
-    (profiles/r04_posterior_fuzz.txt)."""
+    (profiles/archive/r04_posterior_fuzz.txt)."""
     G = _need_gpu()
     from gpvecchia_amd import api as A
     from oracle import r_side as R
