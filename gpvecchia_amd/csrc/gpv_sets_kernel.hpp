@@ -107,6 +107,9 @@
 #ifndef GPV_OPT_PIVROW
 #define GPV_OPT_PIVROW 1      // 16-lane DPP sweep: the pivot row's elements are read from the pivot row (lane j % 16), not from column
 #endif                        // j of the other rows "by symmetry": consistent elimination, residuals of 1e-16 instead of 1e-13 (round 6)
+#ifndef GPV_PIN_DPP_SRC
+#define GPV_PIN_DPP_SRC(RPL) ((RPL) >= 3)   // pin the sweep's DPP sources to VGPRs ahead of their read where matrix registers get parked in
+#endif                                      // AGPRs (three rows per lane); with two rows nothing is parked and the pins only cost scheduling freedom
 #ifndef GPV_OPT_RCP3
 #define GPV_OPT_RCP3 1        // pivot reciprocal: one third-order step on the v_rcp_f64 seed (3 FMAs) instead of two Newton steps (4)
 #endif
@@ -1337,7 +1340,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         dpp_settle(ylo[q], yhi[q]);                     // VALU write -> DPP read: two wait states
                     }
                 }
-                if constexpr (LPS == 16 && GPV_OPT_PIVROW != 0) {                 // (the first two DPP sources of this pivot: see below)
+                if constexpr (LPS == 16 && GPV_OPT_PIVROW != 0 && GPV_PIN_DPP_SRC(RPL)) {   // (the first two DPP sources of this pivot: see below)
                     if constexpr (j + 1 < P) asm volatile("" : "+v"(a[qj][j + 1]));
                     if constexpr (j + 2 < P) asm volatile("" : "+v"(a[qj][j + 2]));
                 }
@@ -1368,7 +1371,7 @@ __global__ void __launch_bounds__((wpb<P, D, COV>() * 64), Geo<P>::MINW) gpv_set
                         //  pressure -- three rows per lane at P = 41 -- hipcc parks matrix registers in AGPRs and fetches them back
                         //  with v_accvgpr_read right in front of their use, a VALU write the inline-asm DPP read would not wait
                         //  for; tools/dpp_hazard_scan.py checks every built object for exactly that)
-                        if constexpr (c + 2 < P) asm volatile("" : "+v"(a[qj][c + 2]));
+                        if constexpr (GPV_PIN_DPP_SRC(RPL) && c + 2 < P) asm volatile("" : "+v"(a[qj][c + 2]));
 #pragma unroll
                         for (int q = Q0; q < RPL; ++q)
                             if (q != qj) dpp_fmac<j % 16>(a[q][c], a[qj][c], nw[q]);
