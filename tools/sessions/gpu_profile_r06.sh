@@ -18,12 +18,3 @@ tail -4 gpurun_out/r06S/levels.txt
 bash tools/sessions/pmc_post.sh gpurun_out/r06S/pmc 2>&1 | tail -3
 cd $GRAFT_REPO_ROOT
 tail -c 600 gpurun_out/r06/bench.json
-# general nu, third form: the all-FP64 rows with two four-wave workgroups per CU (4-octave window)
-for rep in 1 2; do for lib in base f64w4 f64; do
-  if [ $lib = base ]; then unset GPV_LIB; else export GPV_LIB=$GRAFT_REPO_ROOT/gpvecchia_amd/libgpvecchia_hip_$lib.so; fi
-  python bench.py --nu 1.1 --no-secondary --no-cpu-baseline --steps 20 --warmup 5 2>/dev/null | python3 -c "
-import sys, json
-j = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
-print('$lib rep $rep nu=1.1: evals/s %.1f kernel_ms %.4f' % (j['value'], j['roofline']['kernel_ms']))" | tee -a gpurun_out/r06/nu_ab2.txt
-done; done
-unset GPV_LIB
