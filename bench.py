@@ -172,11 +172,12 @@ def time_oracle_function(ms, threads, repeats, probe=None):
 def cpu_baseline(locs, revNN, revCond, covparms, tau, rows_sample, repeats=3, keep=None, sweep=True, probe=None):
     """Time the oracle's C restatement of U_NZentries (src/U_NZentries.cpp:37-69; OpenMP schedule(static)) on the
     conditioning sets [a, b) of the SAME workload (the whole data set when it fits the time budget).  The arguments are
-    marshalled once, outside the timer; the timed callable is the C function.  `value` is quoted on all logical CPUs (the
-    reference's own choice: Ncores = detectCores(logical=TRUE), R/U_sparsity.R:76); `thread_sweep` repeats the function on
-    {1, physical cores, all logical CPUs} (1 thread: on a bounded row sample).  keep: a dict that receives the oracle's U
-    entries of those sets (`Lentries`, rows a..b-1) for the parity_in_run block — the checker's output is compared with
-    the GPU's, never fed back into it."""
+    marshalled once, outside the timer; the timed callable is the C function.  `thread_sweep` repeats the call on {1, 8, 16,
+    32, 64, physical cores, all logical CPUs} (1 thread: on a bounded row sample), each entry with the CPU seconds it was
+    really granted; `value` quotes the FASTEST entry (a container may see every CPU of the box and be held to a few by its
+    quota), `all_logical` the reference's own choice (Ncores = detectCores(logical=TRUE), R/U_sparsity.R:76).  keep: a dict
+    that receives the oracle's U entries of those sets (`Lentries`, rows a..b-1) for the parity_in_run block — the
+    checker's output is compared with the GPU's, never fed back into it."""
     a, b = rows_sample
     n = locs.shape[0]
     logical, physical = host_cpu_topology()
