@@ -549,6 +549,38 @@ def test_rows_are_backward_stable_like_lapack(m):
     assert rh.max() < 1e-12, (m, np.median(rh), rh.max())                         # (they reached 1e-10 .. 4e-9)
 
 
+@pytest.mark.parametrize("covmodel,cp", [("matern", [0.9, 0.25, 1.1]), ("matern", [1.2, 0.3, 0.5]), ("esqe", [0.8, 0.3, 0.4, 0.25])])
+def test_rows_are_backward_stable_other_covariances(covmodel, cp):
+    """The same residual check for the table path (general nu), the exponential and the esqe covariance at m = 30 and 60: the
+    sweep is shared, the covariance evaluation differs.  S from the oracle's double-precision covariance functions (their
+    1e-16 relative error is below the thresholds); all-latent sets."""
+    import warnings
+    G = _need_gpu()
+    from oracle import r_side as R
+    for m in (30, 60):
+        rng = np.random.default_rng(90 + m)
+        n = 900
+        locs = rng.random((n, 2))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            va = R.vecchia_specify(locs, m, ordering="none", cond_yz="y")
+        prep, lo = va["U_prep"], va["locsord"]
+        tau = np.full(n, 1e-6)
+        out = G.U_NZentries(1, n, lo, prep["revNNarray"], prep["revCond"], tau, tau, covmodel, cp)
+        assert out["n_failed"] == 0
+        K = (R.MaternFun if covmodel == "matern" else R.EsqeFun)(R.rdist(lo), cp)
+        res = np.empty(n)
+        for k in range(n):
+            ok = ~np.isnan(prep["revNNarray"][k])
+            J = prep["revNNarray"][k, ok].astype(int) - 1
+            S = K[np.ix_(J, J)].astype(np.longdouble)
+            x = out["Lentries"][k, :len(J)].astype(np.longdouble)
+            rhs = np.zeros(len(J), dtype=np.longdouble)
+            rhs[-1] = 1 / x[-1]
+            res[k] = float(np.abs(S @ x - rhs).max() / (np.abs(S) @ np.abs(x)).max())
+        assert np.median(res) < 2e-14 and res.max() < 1e-11, (covmodel, cp, m, np.median(res), res.max())
+
+
 def test_literal_dropin_failure_behind_a_speculative_evaluation_leaves_no_stale_rows():
     """gpv_U_NZentries evaluates a cached plan of the right SHAPE at once and hashes the arrays meanwhile: its U
     entries are in the caller's buffer before the hash has spoken.  When the hash then misses and the rebuild fails (here: an
